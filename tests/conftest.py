@@ -1,0 +1,38 @@
+"""Shared test plumbing: marker registration, import paths, fixture loaders."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "cuda-recommender_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CASES = ("tiny", "small", "edge")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Returns (fixture dict, RatingData) for tests/golden/<name>.npz (plain arrays only)."""
+    from mfx import dataset as ds
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    d = ds.RatingData(int(g["rows"][0]), int(g["cols"][0]), g["csr_row_ptr"], g["csr_col_idx"], g["csr_val"],
+                      g["csc_col_ptr"], g["csc_row_idx"], g["csc_val"], g["test_row"], g["test_col"], g["test_val"])
+    d.validate()
+    return g, d
+
+
+@pytest.fixture(params=CASES)
+def golden(request):
+    return (request.param,) + load_golden(request.param)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
