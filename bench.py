@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- CCD++ outer-iteration throughput on MI355X (BASELINE.json metric:
+"rating-nnz/sec per CCD++ outer iter at k=64").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is ONE full CCD++ outer iteration (all k ranks: subtract + add-back + v-sweep + u-sweep
+for every rank, T = 1) over a synthetic Netflix-shaped rating matrix that is generated in HBM
+(SURVEY.md 8d workload (i): 480189 x 17770, Z = 99 072 112, k = 64, lambda = 0.05).  With N > 1
+every rank owns one user-row block of that size (weak scaling: the global matrix has N x the
+rows and N x the non-zeros) and the ranks exchange one RCCL all-reduce of the (g, h) column
+partials per inner iteration.  Inputs are resident in HBM when the timed region starts.
+
+The JSON line also carries
+  roofline      the dominant kernel's algorithmic bytes / its mean launch time (HIP events on the
+                solver's own stream, second pass over the same K steps) against 8 TB/s
+  cpu_baseline  the CPU oracle (bit-exact restatement of the reference's ccdr1_OMP) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "cuda-recommender_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=480189)
+    ap.add_argument("--cols", type=int, default=17770)
+    ap.add_argument("--nnz", type=int, default=99072112)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--lam", type=float, default=0.05)
+    ap.add_argument("--inner", type=int, default=1)
+    ap.add_argument("--schedule", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--tiles", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import mfx  # after torch: one HIP runtime / one RCCL in the process
+    from mfx import synth_torch
+    if mfx.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU; libmfx has no CPU path: " + mfx.lib().mfx_last_error().decode())
+
+    # ---------------- synthetic input, generated in HBM ----------------
+    t0 = time.time()
+    d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed + 7919 * rank, device=dev)
+    nnz_local = int(d["csr_val"].numel())
+    col_cnt = (d["csc_col_ptr"][1:] - d["csc_col_ptr"][:-1]).to(torch.int32).contiguous()
+    nnz_tot = torch.tensor([nnz_local, int(d["test_val"].numel())], dtype=torch.int64, device=dev)
+    comm = None
+    if world > 1:
+        dist.all_reduce(col_cnt)
+        dist.all_reduce(nnz_tot)
+        uid = [mfx.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = mfx.Comm(uid[0], rank, world, local_rank)
+    nnz_global, ntest_global = int(nnz_tot[0]), int(nnz_tot[1])
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+
+    p = mfx.parameter()
+    p.k, p.lambda_, p.maxinneriter, p.device = a.k, a.lam, a.inner, local_rank
+    p.schedule, p.kernel_variant, p.tiles_per_span = a.schedule, a.variant, a.tiles
+    solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt if comm else None,
+                           global_test_nnz=ntest_global, device_arrays=d)
+    W0 = mfx.initial_col(a.k, int(d["rows"]))  # reference init (glibc rand, seed 0), src/tools.cpp:165-173
+    solver.set_factors(W0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---------------- warmup, then EXACTLY K timed steps ----------------
+    if a.warmup > 0:
+        solver.iterate(a.warmup, with_rmse=False)
+    sync()
+    t0 = time.perf_counter()
+    solver.iterate(a.steps, with_rmse=False)  # blocks until the solver's stream has drained
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te[0])
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = nnz_global / (elapsed / a.steps)
+
+    # ---------------- roofline: same K steps again, every launch bracketed by HIP events ------------
+    solver.set_profile(True)
+    solver.iterate(a.steps, with_rmse=False)
+    ktimes = solver.kernel_times()
+    solver.set_profile(False)
+    m, n, Z = int(d["rows"]), int(d["cols"]), nnz_local
+    flags = Z / 8.0
+    # algorithmic bytes per launch (DESIGN.md "bytes per kernel"): idx + val read + val write per
+    # non-zero, head flags, one compulsory read of each operand pack, the partial-sum outputs
+    alg = {
+        "ccd_fused_csc_pass": 12.0 * Z + flags + 8.0 * m + 8.0 * n + 8.0 * n,
+        "ccd_fused_csr_pass": 12.0 * Z + flags + 16.0 * n + 8.0 * m + 8.0 * m,
+        "ccd_flat_sweep": 8.0 * Z + flags + 4.0 * max(m, n) + 8.0 * min(m, n),
+        "ccd_flat_resid": 12.0 * Z + flags + 4.0 * (m + n),
+        "ccd_wave_sweep": 8.0 * Z + 4.0 * (m + n) + 8.0 * min(m, n),
+        "ccd_wave_resid": 12.0 * Z + 4.0 * (m + n),
+    }
+    roofline = None
+    dom = None
+    if ktimes:
+        cand = {kname: v for kname, v in ktimes.items() if kname in alg}
+        if cand:
+            dom = max(cand, key=lambda kn: cand[kn][0])
+            secs, launches = cand[dom]
+            avg = secs / max(1, launches)
+            achieved = alg[dom] / avg / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    ent = tj.get(dom)
+                    if ent and int(ent.get("nnz", -1)) == Z:
+                        traffic = ent.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
+                        "algorithmic_bytes_per_launch": int(alg[dom]),
+                        "as_written_equiv_frac": round(a.k * (48 + 16 * a.inner) * nnz_global /
+                                                       (elapsed / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
+    kernels = {kn: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1]),
+                    "avg_us": round(v[0] / max(1, v[1]) * 1e6, 2)} for kn, v in (ktimes or {}).items()}
+
+    rep = solver.iterate(1, with_rmse=True)  # one more iteration, just to report a test RMSE
+    rmse_now = rep[0].rmse
+
+    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) --------
+    cpu_baseline = None
+    if world == 1 and not a.no_cpu_baseline:
+        from oracle import oracle as orc
+        host = synth_torch.to_rating_data(d)
+        threads = orc.max_threads()
+        ks = max(1, min(a.cpu_ranks, a.k))
+        Wc = np.ascontiguousarray(W0[:ks])
+        _, _, _, times, _, _ = orc.ccdr1(host, Wc, ks, a.lam, 2, a.inner, threads)
+        t_steady = float(times[1].sum())  # outer iteration 2: includes the add-back (src/CCD.cpp:100)
+        t_outer_k = t_steady * (a.k / ks)
+        cpu_baseline = {"value": round(host.nnz / t_outer_k, 1), "unit": "nnz/s", "cores": threads, "kind": "port",
+                        "sample": f"{ks} of {a.k} ranks, outer iterations 1-2 on the full matrix; steady-state "
+                                  f"iteration 2 ({t_steady:.2f} s) scaled by {a.k}/{ks}"}
+    solver.close()
+
+    if rank == 0:
+        out = {
+            "metric": "rating-nnz/sec per CCD++ outer iter at k=64", "value": round(value, 1), "unit": "nnz/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Netflix-shaped synthetic (BASELINE configs[2]): per-GPU "
+                                   f"{a.rows}x{a.cols}, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam}",
+                       "rows_per_gpu": a.rows, "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
+                       "inner_iters": a.inner, "schedule": "fused" if a.schedule == 1 else "as-written",
+                       "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "test_rmse_after": round(rmse_now, 6), "gen_seconds": round(gen_s, 2),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

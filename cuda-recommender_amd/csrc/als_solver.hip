@@ -1,0 +1,496 @@
+// als_solver.hip -- ALS kernels (gfx950) and host orchestration.
+//
+// Kernel shape.  One wavefront per work item; a work item is a whole segment, or a chunk of a long
+// one (AlsHalf::build).  The gathered factor rows go straight from global memory into the MFMA
+// operand layout: for v_mfma_f32_32x32x2_f32 lane l supplies A[i = l&31][kk = l>>5] and
+// B[kk = l>>5][j = l&31], so lane l loads X[row(q0 + (l>>5))][32*I + (l&31)] -- two gathered rows
+// per instruction, each read as contiguous 128-byte pieces.  The same register is the A operand
+// of tile (I, J) and the B operand of tile (J', I): no LDS staging, no cross-lane traffic.
+// Only the upper block triangle is accumulated (NT*(NT+1)/2 tiles of 16 accumulator registers).
+// fp32 MFMA is an exact k-ordered fmaf chain, so results are reproducible run to run.
+//
+// Tail (per segment, still one wave): accumulators -> LDS (row stride kp+1: conflict-free column
+// walks), + lambda on the diagonal (plain lambda, src/ALS.cpp:120-122), left-looking Cholesky in
+// the reference's own operation order (src/ALS.cpp:6-23), then L z = b and L^T y = z instead of
+// the reference's explicit inverse (same solution up to rounding; tolerance in the tests).
+#include "als_solver.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "ccd_kernels.hpp"
+
+namespace mfx {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct AlsArgs {
+    const AlsItem* items;
+    const AlsReduce* reduces;
+    uint32_t count;  // items (gram kernel) or reduces (reduce kernel)
+    const uint32_t* idx;
+    const float* val;
+    const float* X;
+    float* Y;
+    uint32_t k;
+    float lambda;
+    float* ws;
+    uint32_t* spd_fail;
+    float* gram_out;  // != nullptr: dump the k x k Gramian (no lambda) of item 0 and stop
+};
+
+template <int NT> struct Tiles { static constexpr int kCount = NT * (NT + 1) / 2; };
+
+template <int NT>
+__device__ __forceinline__ size_t slot_floats() { return (size_t) Tiles<NT>::kCount * 1024 + (size_t) NT * 64; }
+
+// Accumulators + rhs -> LDS, Cholesky, two triangular solves, Y[seg] <- solution.
+template <int NT>
+__device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], float* lds,
+                           const AlsArgs& a, uint32_t seg) {
+    constexpr int KP = 32 * NT;
+    constexpr int LD = KP + 1;
+    const uint32_t lane = threadIdx.x & 63, c31 = lane & 31, h = lane >> 5;
+    const int k = (int) a.k;
+    float* L = lds;
+    float* bv = lds + (size_t) KP * LD;
+    {
+        int ti = 0;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+#pragma unroll
+            for (int J = I; J < NT; ++J, ++ti) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = I * 32 + (r & 3) + 8 * (r >> 2) + 4 * (int) h;
+                    const int col = J * 32 + (int) c31;
+                    const float x = acc[ti][r];
+                    L[row * LD + col] = x;
+                    L[col * LD + row] = x;
+                }
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            const float t = bacc[I] + __shfl_xor(bacc[I], 32, 64);
+            if (h == 0) bv[I * 32 + c31] = t;
+        }
+    }
+    __syncthreads();
+    if (a.gram_out) {
+        for (int e = (int) lane; e < k * k; e += 64) a.gram_out[e] = L[(e / k) * LD + (e % k)];
+        return;
+    }
+    for (int i = (int) lane; i < k; i += 64) L[i * LD + i] = __fadd_rn(L[i * LD + i], a.lambda);
+    __syncthreads();
+
+    // Left-looking Cholesky on the lower triangle, row i of the reference's loop at a time:
+    //   sum = A[i][j] - sum_{q = i-1..0} L[i][q] * L[j][q];  j == i: p = sqrt(sum);  else L[j][i] = sum / p
+    for (int i = 0; i < k; ++i) {
+        float p = 0.f;
+        for (int j0 = i; j0 < k; j0 += 64) {
+            const int j = j0 + (int) lane;
+            float sum = 0.f;
+            if (j < k) {
+                sum = L[j * LD + i];
+                for (int q = i - 1; q >= 0; --q) sum = __fsub_rn(sum, __fmul_rn(L[i * LD + q], L[j * LD + q]));
+            }
+            if (j0 == i) {  // lane 0 holds the pivot of this row
+                const float piv = __shfl(sum, 0, 64);
+                if (lane == 0 && !(piv > 0.f)) atomicAdd(a.spd_fail, 1u);
+                p = sqrtf(piv);
+            }
+            if (j < k) L[j * LD + i] = (j == i) ? p : sum / p;
+        }
+        __syncthreads();
+    }
+    // forward substitution L z = b (column oriented; lane r owns row r, two rows per lane for k > 64)
+    float z0 = lane < (uint32_t) k ? bv[lane] : 0.f;
+    float z1 = (NT > 2 && lane + 64 < (uint32_t) k) ? bv[lane + 64] : 0.f;
+    for (int i = 0; i < k; ++i) {
+        const float src = (NT > 2 && i >= 64) ? z1 : z0;
+        const float zi = __shfl(src, i & 63, 64) / L[i * LD + i];
+        if ((int) lane == i) z0 = zi;
+        if (NT > 2 && (int) lane + 64 == i) z1 = zi;
+        if ((int) lane > i && (int) lane < k) z0 = __fsub_rn(z0, __fmul_rn(L[lane * LD + i], zi));
+        if (NT > 2 && (int) lane + 64 > i && (int) lane + 64 < k) z1 = __fsub_rn(z1, __fmul_rn(L[(lane + 64) * LD + i], zi));
+    }
+    // back substitution L^T y = z
+    for (int i = k - 1; i >= 0; --i) {
+        const float src = (NT > 2 && i >= 64) ? z1 : z0;
+        const float yi = __shfl(src, i & 63, 64) / L[i * LD + i];
+        if ((int) lane == i) z0 = yi;
+        if (NT > 2 && (int) lane + 64 == i) z1 = yi;
+        if ((int) lane < i) z0 = __fsub_rn(z0, __fmul_rn(L[i * LD + lane], yi));
+        if (NT > 2 && (int) lane + 64 < i) z1 = __fsub_rn(z1, __fmul_rn(L[i * LD + lane + 64], yi));
+    }
+    float* y = a.Y + (size_t) seg * k;
+    if ((int) lane < k) y[lane] = z0;
+    if (NT > 2 && (int) lane + 64 < k) y[lane + 64] = z1;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t lane = threadIdx.x & 63, c31 = lane & 31, h = lane >> 5;
+    const uint32_t item = blockIdx.x;
+    if (item >= a.count) return;
+    const AlsItem it = a.items[item];
+    const uint32_t k = a.k;
+    if (it.hi == it.lo) {  // empty segment: zero vector (src/ALS.cpp:151-157)
+        for (uint32_t c = lane; c < k; c += 64) a.Y[(size_t) it.seg * k + c] = 0.f;
+        return;
+    }
+    f32x16 acc[Tiles<NT>::kCount];
+    float bacc[NT];
+#pragma unroll
+    for (int t = 0; t < Tiles<NT>::kCount; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int I = 0; I < NT; ++I) bacc[I] = 0.f;
+
+    constexpr int U = 4;  // gathered row pairs in flight per wave
+    for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 2 * U) {
+        float av[U][NT], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 2 * u + h;
+            const bool ok = q < it.hi;
+            const uint32_t row = ok ? a.idx[q] : 0u;
+            rv[u] = ok ? a.val[q] : 0.f;
+            const float* x = a.X + (size_t) row * k;
+#pragma unroll
+            for (int I = 0; I < NT; ++I) {
+                const uint32_t col = I * 32 + c31;
+                av[u][I] = (ok && col < k) ? x[col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int ti = 0;
+#pragma unroll
+            for (int I = 0; I < NT; ++I) {
+                bacc[I] += rv[u] * av[u][I];
+#pragma unroll
+                for (int J = I; J < NT; ++J, ++ti)
+                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][I], av[u][J], acc[ti], 0, 0, 0);
+            }
+        }
+    }
+    if (it.slot >= 0) {  // chunk of a long segment: park the raw accumulators, the reducer finishes
+        float* w = a.ws + (size_t) it.slot * slot_floats<NT>();
+#pragma unroll
+        for (int t = 0; t < Tiles<NT>::kCount; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[t * 1024 + r * 64 + lane] = acc[t][r];
+#pragma unroll
+        for (int I = 0; I < NT; ++I) w[Tiles<NT>::kCount * 1024 + I * 64 + lane] = bacc[I];
+        return;
+    }
+    solve_tail<NT>(acc, bacc, lds, a, it.seg);
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void k_als_reduce(AlsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    if (blockIdx.x >= a.count) return;
+    const AlsReduce rd = a.reduces[blockIdx.x];
+    f32x16 acc[Tiles<NT>::kCount];
+    float bacc[NT];
+#pragma unroll
+    for (int t = 0; t < Tiles<NT>::kCount; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int I = 0; I < NT; ++I) bacc[I] = 0.f;
+    for (uint32_t s = 0; s < rd.nslots; ++s) {  // chunk order: deterministic
+        const float* w = a.ws + (size_t) (rd.slot0 + s) * slot_floats<NT>();
+#pragma unroll
+        for (int t = 0; t < Tiles<NT>::kCount; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += w[t * 1024 + r * 64 + lane];
+#pragma unroll
+        for (int I = 0; I < NT; ++I) bacc[I] += w[Tiles<NT>::kCount * 1024 + I * 64 + lane];
+    }
+    solve_tail<NT>(acc, bacc, lds, a, rd.seg);
+}
+
+template <int NT>
+int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
+    constexpr int KP = 32 * NT;
+    const size_t lds_bytes = ((size_t) KP * (KP + 1) + KP) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds_bytes > 48 * 1024) {
+        MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_gram<NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+        MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_reduce<NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+        attr_set = true;
+    }
+    AlsArgs a = base;
+    if (nitems) {
+        a.count = nitems;
+        hipLaunchKernelGGL(k_als_gram<NT>, dim3(nitems), dim3(64), lds_bytes, st, a);
+        MFX_HIP(hipGetLastError());
+    }
+    if (nreduces) {
+        a.count = nreduces;
+        hipLaunchKernelGGL(k_als_reduce<NT>, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        MFX_HIP(hipGetLastError());
+    }
+    return MFX_OK;
+}
+
+int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
+    const uint32_t nt = (a.k + 31) / 32;
+    switch (nt) {
+        case 1: return launch_half_nt<1>(a, nitems, nreduces, st);
+        case 2: return launch_half_nt<2>(a, nitems, nreduces, st);
+        case 3: return launch_half_nt<3>(a, nitems, nreduces, st);
+        case 4: return launch_half_nt<4>(a, nitems, nreduces, st);
+        default: return fail(MFX_ERR_INVALID, "ALS: rank k = %u not supported (1 <= k <= 128)", a.k);
+    }
+}
+
+constexpr uint32_t kAlsChunk = 1024;  // gathered rows per wavefront before a segment is split
+
+}  // namespace
+
+size_t als_ws_floats(uint32_t nslots, uint32_t k) {
+    const size_t nt = (k + 31) / 32;
+    return (size_t) nslots * (nt * (nt + 1) / 2 * 1024 + nt * 64);
+}
+
+int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, const uint32_t* ptr_in, const uint32_t* idx_in,
+                   const float* val_in, mfx_memspace space, uint32_t chunk, hipStream_t st) {
+    nseg = nseg_;
+    nnz = nnz_;
+    std::vector<uint32_t> hp((size_t) nseg + 1);
+    if (space == MFX_DEVICE) MFX_HIP(hipMemcpy(hp.data(), ptr_in, sizeof(uint32_t) * hp.size(), hipMemcpyDeviceToHost));
+    else memcpy(hp.data(), ptr_in, sizeof(uint32_t) * hp.size());
+    MFX_REQUIRE(hp[0] == 0 && hp[nseg] == nnz, "segment pointer array does not span [0, nnz]");
+    std::vector<AlsItem> it;
+    std::vector<AlsReduce> rd;
+    it.reserve((size_t) nseg + nnz / chunk + 1);
+    uint32_t slots = 0;
+    for (uint32_t s = 0; s < nseg; ++s) {
+        MFX_REQUIRE(hp[s] <= hp[s + 1], "segment pointer array is not monotone at %u", s);
+        const uint32_t lo = hp[s], hi = hp[s + 1];
+        if (hi - lo <= chunk) {
+            it.push_back(AlsItem{s, lo, hi, -1});
+        } else {
+            const uint32_t pieces = (hi - lo + chunk - 1) / chunk;
+            rd.push_back(AlsReduce{s, slots, pieces});
+            for (uint32_t c = 0; c < pieces; ++c)
+                it.push_back(AlsItem{s, lo + c * chunk, std::min(hi, lo + (c + 1) * chunk), (int32_t) (slots + c)});
+            slots += pieces;
+        }
+    }
+    nitems = (uint32_t) it.size();
+    nreduces = (uint32_t) rd.size();
+    nslots = slots;
+    MFX_TRY(ptr.alloc(hp.size())); MFX_TRY(ptr.upload(hp.data(), hp.size(), MFX_HOST, st));
+    MFX_TRY(idx.alloc(nnz ? nnz : 1)); MFX_TRY(idx.upload(idx_in, nnz, space, st));
+    MFX_TRY(val.alloc(nnz ? nnz : 1)); MFX_TRY(val.upload(val_in, nnz, space, st));
+    MFX_TRY(items.alloc(nitems ? nitems : 1)); MFX_TRY(items.upload(it.data(), nitems, MFX_HOST, st));
+    MFX_TRY(reduces.alloc(nreduces ? nreduces : 1)); MFX_TRY(reduces.upload(rd.data(), nreduces, MFX_HOST, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    return MFX_OK;
+}
+
+int als_half_launch(const AlsHalf& h, const float* X, float* Y, uint32_t k, float lambda, float* ws,
+                    uint32_t* spd_fail, hipStream_t st) {
+    AlsArgs a{};
+    a.items = h.items.get(); a.reduces = h.reduces.get(); a.idx = h.idx.get(); a.val = h.val.get();
+    a.X = X; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
+    return launch_half(a, h.nitems, h.nreduces, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+int AlsSolver::create(AlsSolver** out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space) {
+    MFX_REQUIRE(out && R && p, "mfx_als_create: null argument");
+    std::unique_ptr<AlsSolver> s(new AlsSolver());
+    MFX_TRY(s->init(R, T, p, space));
+    *out = s.release();
+    return MFX_OK;
+}
+
+AlsSolver::~AlsSolver() {
+    (void) hipSetDevice(device_);
+    for (hipEvent_t& e : ev_)
+        if (e) (void) hipEventDestroy(e);
+    if (st_) {
+        (void) hipStreamSynchronize(st_);
+        (void) hipStreamDestroy(st_);
+    }
+}
+
+int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space) {
+    MFX_REQUIRE(R->rows > 0 && R->cols > 0 && R->nnz >= 0, "bad matrix shape");
+    MFX_REQUIRE(R->rows < (int64_t) 0xFFFFFFFFll && R->cols < (int64_t) 0xFFFFFFFFll &&
+                    R->nnz < (int64_t) 0xFFFF0000ll, "matrix exceeds 32-bit index range");
+    MFX_REQUIRE(p->k >= 1 && p->k <= 128, "ALS: rank k = %u not supported (1 <= k <= 128)", p->k);
+    MFX_REQUIRE(R->csc_col_ptr && R->csr_row_ptr, "null CSR/CSC pointer array");
+    p_ = *p;
+    device_ = p->device;
+    MFX_TRY(use_device(device_));
+    MFX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    for (hipEvent_t& e : ev_) MFX_HIP(hipEventCreate(&e));
+    m_ = (uint32_t) R->rows; n_ = (uint32_t) R->cols; k_ = p->k;
+    // W-half walks CSR rows with csr_val (src/ALS.cpp:132), H-half walks CSC columns
+    MFX_TRY(rows_.build(m_, (uint64_t) R->nnz, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, kAlsChunk, st_));
+    MFX_TRY(cols_.build(n_, (uint64_t) R->nnz, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, kAlsChunk, st_));
+    MFX_TRY(W_.alloc_zero((size_t) m_ * k_, st_));
+    MFX_TRY(H_.alloc_zero((size_t) n_ * k_, st_));
+    MFX_TRY(ws_.alloc(std::max<size_t>(1, als_ws_floats(std::max(rows_.nslots, cols_.nslots), k_))));
+    MFX_TRY(spd_fail_.alloc_zero(1, st_));
+    nnz_test_ = T ? T->nnz : 0;
+    if (nnz_test_ > 0) {
+        MFX_REQUIRE(T->row && T->col && T->val, "null test array");
+        MFX_TRY(t_row_.alloc(nnz_test_)); MFX_TRY(t_row_.upload(T->row, nnz_test_, space, st_));
+        MFX_TRY(t_col_.alloc(nnz_test_)); MFX_TRY(t_col_.upload(T->col, nnz_test_, space, st_));
+        MFX_TRY(t_val_.alloc(nnz_test_)); MFX_TRY(t_val_.upload(T->val, nnz_test_, space, st_));
+    }
+    MFX_TRY(rmse_partials_.alloc_zero(kRmseBlocks, st_));
+    MFX_TRY(rmse_sum_.alloc_zero(1, st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    return MFX_OK;
+}
+
+int AlsSolver::set_factors(const float* W, const float* H, mfx_memspace space) {
+    // W's initial content is irrelevant (overwritten before its first read, src/ALS.cpp:98-158)
+    MFX_REQUIRE(H, "mfx_als_set_factors: H is required");
+    MFX_TRY(use_device(device_));
+    if (W) MFX_TRY(W_.upload(W, (size_t) m_ * k_, space, st_));
+    MFX_TRY(H_.upload(H, (size_t) n_ * k_, space, st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    factors_set_ = true;
+    return MFX_OK;
+}
+
+int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
+    MFX_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
+    MFX_REQUIRE(factors_set_, "mfx_als_iterate: call mfx_als_set_factors first");
+    MFX_TRY(use_device(device_));
+    for (int it = 0; it < n_iter; ++it) {
+        MFX_HIP(hipMemsetAsync(spd_fail_.get(), 0, sizeof(uint32_t), st_));
+        MFX_HIP(hipEventRecord(ev_[0], st_));
+        MFX_TRY(als_half_launch(rows_, H_.get(), W_.get(), k_, p_.lambda, ws_.get(), spd_fail_.get(), st_));
+        MFX_HIP(hipEventRecord(ev_[1], st_));
+        MFX_TRY(als_half_launch(cols_, W_.get(), H_.get(), k_, p_.lambda, ws_.get(), spd_fail_.get(), st_));
+        MFX_HIP(hipEventRecord(ev_[2], st_));
+        double rmse = 0.0, sum = 0.0;
+        if (with_rmse && nnz_test_ > 0) {
+            MFX_TRY(launch_test_sqerr(nnz_test_, t_row_.get(), t_col_.get(), t_val_.get(), W_.get(), H_.get(), m_, n_,
+                                      k_, 1, rmse_partials_.get(), kRmseBlocks, rmse_sum_.get(), st_));
+            MFX_HIP(hipMemcpyAsync(&sum, rmse_sum_.get(), sizeof(double), hipMemcpyDeviceToHost, st_));
+        }
+        MFX_HIP(hipEventRecord(ev_[3], st_));
+        uint32_t bad = 0;
+        MFX_HIP(hipMemcpyAsync(&bad, spd_fail_.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
+        MFX_HIP(hipStreamSynchronize(st_));
+        if (with_rmse && nnz_test_ > 0) rmse = std::sqrt(sum / (double) nnz_test_);
+        float ms_w = 0.f, ms_h = 0.f, ms_r = 0.f;
+        MFX_HIP(hipEventElapsedTime(&ms_w, ev_[0], ev_[1]));
+        MFX_HIP(hipEventElapsedTime(&ms_h, ev_[1], ev_[2]));
+        MFX_HIP(hipEventElapsedTime(&ms_r, ev_[2], ev_[3]));
+        t_half_[0] += ms_w * 1e-3; t_half_[1] += ms_h * 1e-3; n_half_[0]++; n_half_[1]++;
+        mfx_iter_report rep;
+        rep.rank_time = 0.0;
+        rep.update_time = (ms_w + ms_h) * 1e-3;
+        rep.rmse = rmse;
+        rep.rmse_time = ms_r * 1e-3;
+        update_acc_ += rep.update_time;
+        ++iter_;
+        if (reports) reports[it] = rep;
+        // the reference prints this from inside the kernel for every failing pivot (ALS_CUDA.cu:11-13)
+        if (bad && p_.verbose) printf(" a is not positive definite! (%u pivots)\n", bad);
+        if (p_.verbose) {
+            // log line format of cuda_src/ALS_CUDA.cu:360-361
+            printf("[-INFO-] iteration num %d \tupdate_time %.4lf|%.4lfs \tRMSE=%lf time:%fs\n", (int) iter_,
+                   rep.update_time, update_acc_, rep.rmse, rep.rmse_time);
+            fflush(stdout);
+        }
+    }
+    return MFX_OK;
+}
+
+int AlsSolver::get_factors(float* W, float* H, mfx_memspace space) {
+    MFX_TRY(use_device(device_));
+    const hipMemcpyKind kind = space == MFX_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (W) MFX_HIP(hipMemcpyAsync(W, W_.get(), sizeof(float) * (size_t) m_ * k_, kind, st_));
+    if (H) MFX_HIP(hipMemcpyAsync(H, H_.get(), sizeof(float) * (size_t) n_ * k_, kind, st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    return MFX_OK;
+}
+
+int AlsSolver::kernel_times(int cap, const char** names, double* seconds, int64_t* launches) {
+    static const char* nm[2] = {"als_half_rows(W over H)", "als_half_cols(H over W)"};
+    int n = 0;
+    for (int i = 0; i < 2 && n < cap; ++i) {
+        if (!n_half_[i]) continue;
+        if (names) names[n] = nm[i];
+        if (seconds) seconds[n] = t_half_[i];
+        if (launches) launches[n] = n_half_[i];
+        ++n;
+    }
+    t_half_[0] = t_half_[1] = 0; n_half_[0] = n_half_[1] = 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct OpStream {
+    hipStream_t st = nullptr;
+    ~OpStream() { if (st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); } }
+};
+}  // namespace
+
+int als_gramian_op(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const float* X, int64_t k, float* A, int device) {
+    MFX_REQUIRE(k <= 128, "ALS: rank k = %lld not supported (1 <= k <= 128)", (long long) k);
+    MFX_TRY(use_device(device));
+    if (cnt == 0) { memset(A, 0, sizeof(float) * k * k); return MFX_OK; }
+    MFX_REQUIRE(cnt <= kAlsChunk, "mfx_als_gramian: at most %u gathered rows per call", kAlsChunk);
+    OpStream os;
+    MFX_HIP(hipStreamCreateWithFlags(&os.st, hipStreamNonBlocking));
+    DevBuf<uint32_t> didx, fail_cnt; DevBuf<float> dval, dX, dY, dA; DevBuf<AlsItem> ditem;
+    MFX_TRY(didx.alloc(cnt)); MFX_TRY(didx.upload(idx, cnt, MFX_HOST, os.st));
+    MFX_TRY(dval.alloc_zero(cnt, os.st));
+    MFX_TRY(dX.alloc((size_t) nrows_x * k)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
+    MFX_TRY(dY.alloc_zero(k, os.st)); MFX_TRY(dA.alloc_zero((size_t) k * k, os.st));
+    MFX_TRY(fail_cnt.alloc_zero(1, os.st));
+    AlsItem it{0, 0, (uint32_t) cnt, -1};
+    MFX_TRY(ditem.alloc(1)); MFX_TRY(ditem.upload(&it, 1, MFX_HOST, os.st));
+    AlsArgs a{};
+    a.items = ditem.get(); a.idx = didx.get(); a.val = dval.get(); a.X = dX.get(); a.Y = dY.get();
+    a.k = (uint32_t) k; a.lambda = 0.f; a.spd_fail = fail_cnt.get(); a.gram_out = dA.get();
+    MFX_TRY(launch_half(a, 1, 0, os.st));
+    MFX_HIP(hipMemcpyAsync(A, dA.get(), sizeof(float) * k * k, hipMemcpyDeviceToHost, os.st));
+    MFX_HIP(hipStreamSynchronize(os.st));
+    return MFX_OK;
+}
+
+int als_half_op(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
+                int64_t nrows_x, const float* X, float* Y, int64_t k, float lambda, int device) {
+    MFX_REQUIRE(k <= 128, "ALS: rank k = %lld not supported (1 <= k <= 128)", (long long) k);
+    MFX_TRY(use_device(device));
+    OpStream os;
+    MFX_HIP(hipStreamCreateWithFlags(&os.st, hipStreamNonBlocking));
+    AlsHalf h;
+    MFX_TRY(h.build((uint32_t) nseg, (uint64_t) nnz, ptr, idx, val, MFX_HOST, kAlsChunk, os.st));
+    DevBuf<float> dX, dY, ws; DevBuf<uint32_t> fail_cnt;
+    MFX_TRY(dX.alloc((size_t) nrows_x * k)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
+    MFX_TRY(dY.alloc_zero((size_t) nseg * k, os.st));
+    MFX_TRY(ws.alloc(std::max<size_t>(1, als_ws_floats(h.nslots, (uint32_t) k))));
+    MFX_TRY(fail_cnt.alloc_zero(1, os.st));
+    MFX_TRY(als_half_launch(h, dX.get(), dY.get(), (uint32_t) k, lambda, ws.get(), fail_cnt.get(), os.st));
+    MFX_HIP(hipMemcpyAsync(Y, dY.get(), sizeof(float) * (size_t) nseg * k, hipMemcpyDeviceToHost, os.st));
+    MFX_HIP(hipStreamSynchronize(os.st));
+    return MFX_OK;
+}
+
+}  // namespace mfx

@@ -1,0 +1,85 @@
+// ccd_kernels.hpp -- launchers for the CCD++ device kernels (gfx950, wave64).
+//
+// Two families implement the reference's three CCD kernels (cuda_src/CCD_CUDA.cu:24-104):
+//   wave-per-segment  (variant 0)  one wavefront walks one row/column; simple, used as the
+//                                  in-library cross-check and for the as-written schedule
+//   flat-stream       (variant 1)  nnz-balanced spans over the flat idx/val arrays with head-flag
+//                                  segmented reduction (flat_layout.hpp); also carries the two
+//                                  FUSED passes that the default schedule is built from
+#pragma once
+
+#include "common.hpp"
+
+namespace mfx {
+
+// Device view of one orientation of the residual matrix (CSC: segments = columns, gathered
+// index = row; CSR: the transpose) together with its flat-stream metadata.
+struct SegStreamDev {
+    uint32_t nseg = 0;
+    uint32_t nne = 0;
+    uint64_t nnz = 0;
+    uint32_t nspans = 0;
+    uint32_t tiles_per_span = 0;
+    const uint32_t* ptr = nullptr;             // [nseg+1]
+    const uint32_t* idx = nullptr;             // [padded nnz]
+    float* val = nullptr;                      // [padded nnz]  residual copy, updated in place
+    const uint64_t* flags = nullptr;           // [padded nnz / 64]
+    const int32_t* rank_of_seg = nullptr;      // [nseg]
+    const uint32_t* seg_of_rank = nullptr;     // [nne]
+    const uint32_t* span_rank_base = nullptr;  // [nspans]
+    // reduction scratch written by the flat kernels
+    float* gpart = nullptr;    // [nne]
+    float* hpart = nullptr;    // [nne]
+    float* carry_g = nullptr;  // [nspans]
+    float* carry_h = nullptr;  // [nspans]
+};
+
+enum FlatMode : int {
+    FM_SWEEP = 0,  // g += x*val, h += x*x                      x = gather_f32[idx]
+    FM_RESID = 1,  // val (+/-)= gather_f32[idx] * perseg_f32[seg]
+    FM_FCSC = 2,   // float2 A = gather[idx], float2 B = perseg[seg]:
+                   //   val = (val - A.x*B.x) + A.y*B.y ; g += A.y*val ; h += A.y^2
+    FM_FCSR = 3,   // float4 C = gather[idx], float2 D = perseg[seg]:
+                   //   val = (val - C.x*D.x) + C.y*D.y ; g += C.z*val ; h += C.z^2
+};
+
+// Flat-stream pass over `s`.  gather/perseg element types depend on `mode` (see FlatMode).
+int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg,
+                int add, hipStream_t st);
+
+// Wave-per-segment kernels.
+int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, float* h_dense,
+                      hipStream_t st);
+int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float* per_seg, int add,
+                      hipStream_t st);
+
+// partials + carries of a flat pass -> dense gh[0..nseg) = g, gh[nseg..2nseg) = h (0 for empty).
+int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st);
+
+// Finalize:  x = cnt ? g / (lambda*cnt + h) : 0  for every segment, plus the operand packs the
+// next fused passes read.  Source of (g, h): the flat partials of `s` (gh_dense == nullptr) or a
+// dense, already all-reduced buffer gh_dense[2*nseg].
+struct FinalizeArgs {
+    const float* gh_dense = nullptr;    // [2*nseg] or nullptr
+    const uint32_t* cnt_override = nullptr;  // global |Omega_c| (multi-GPU) or nullptr = ptr diff
+    float lambda = 0.f;
+    float* out_vec = nullptr;           // W[t] / H[t] slice, [nseg]
+    float2* pack2 = nullptr;            // in: (prev_new, cur_old); out: (cur_new, next_old)
+    const float* next_vec = nullptr;    // W[t+1] / H[t+1] slice (old values)
+    float4* pack4 = nullptr;            // out: (prev_new, cur_old, cur_new, 0), may be nullptr
+};
+int launch_finalize(const SegStreamDev& s, const FinalizeArgs& a, hipStream_t st);
+
+// pack[i] = (x ? x[i] : 0, y[i])
+int launch_pack2(uint32_t n, const float* x, const float* y, float2* pack, hipStream_t st);
+
+// Test RMSE: sum over the test set of (pred - val)^2 in fp64 -> *sum_out (device double).
+// reference: GPU_rmse (cuda_src/CUDA_AUX.cu:3-27) + host sum (CCD_CUDA.cu:394-401);
+// arithmetic follows calrmse/dot (src/tools.cpp:184-198,235-248): fp32 products, fp64 sums.
+int launch_test_sqerr(int64_t nnz_test, const uint32_t* row, const uint32_t* col, const float* val,
+                      const float* W, const float* H, int64_t rows, int64_t cols, int64_t k,
+                      int ifALS, double* block_partials, uint32_t nblocks, double* sum_out,
+                      hipStream_t st);
+constexpr uint32_t kRmseBlocks = 1024;
+
+}  // namespace mfx

@@ -1,0 +1,408 @@
+// ccd_solver.hip -- host orchestration of CCD++ on one GPU (or one shard of a multi-GPU run).
+//
+// Replaces ccdpp_NV (cuda_src/CCD_CUDA.cu:224-451).  Differences that are design, not accident:
+//   * one HIP stream, no hipDeviceSynchronize between launches (the reference syncs after every
+//     launch group, CCD_CUDA.cu:197-200,216-219); the host waits once per outer iteration;
+//   * default schedule fuses subtract(t-1) + add-back(t) + the first v-/u-sweep of rank t into
+//     two passes (one over the CSC copy, one over the CSR copy): 24 B/nnz per rank instead of
+//     (48+16T) B/nnz as written.  Arithmetic per element is unchanged (same roundings, same
+//     order of the two updates); only the order of the fp32 reduction differs from the CPU.
+//   * mfx_params.schedule = 0 runs the kernel sequence exactly as written, for A/B and parity.
+#include "ccd_solver.hpp"
+
+#include <cmath>
+
+namespace mfx {
+
+// ------------------------------------------------------------------------------------------------
+int SegStreamStore::build(uint32_t nseg, uint64_t nnz, const uint32_t* ptr, const uint32_t* idx,
+                          const float* val, mfx_memspace space, uint32_t tiles_per_span, hipStream_t st) {
+    std::vector<uint32_t> ptr_host_buf;
+    const uint32_t* ptr_host = ptr;
+    if (space == MFX_DEVICE) {
+        ptr_host_buf.resize((size_t) nseg + 1);
+        MFX_HIP(hipMemcpy(ptr_host_buf.data(), ptr, sizeof(uint32_t) * ((size_t) nseg + 1), hipMemcpyDeviceToHost));
+        ptr_host = ptr_host_buf.data();
+    }
+    MFX_REQUIRE(ptr_host[0] == 0 && ptr_host[nseg] == nnz, "segment pointer array does not span [0, nnz]");
+    for (uint32_t c = 0; c < nseg; ++c)
+        MFX_REQUIRE(ptr_host[c] <= ptr_host[c + 1], "segment pointer array is not monotone at %u", c);
+    build_flat_layout(ptr_host, nseg, nnz, tiles_per_span, &layout_);
+    const FlatLayoutHost& L = layout_;
+
+    MFX_TRY(ptr_.alloc((size_t) nseg + 1));
+    MFX_TRY(ptr_.upload(ptr_host, (size_t) nseg + 1, MFX_HOST, st));
+    MFX_TRY(idx_.alloc_zero(L.padded_nnz, st));
+    MFX_TRY(idx_.upload(idx, nnz, space, st));
+    MFX_TRY(val_.alloc_zero(L.padded_nnz, st));
+    if (val) MFX_TRY(val_.upload(val, nnz, space, st));
+    MFX_TRY(flags_.alloc(L.flags.size()));
+    MFX_TRY(flags_.upload(L.flags.data(), L.flags.size(), MFX_HOST, st));
+    MFX_TRY(rank_of_seg_.alloc(nseg));
+    MFX_TRY(rank_of_seg_.upload(L.rank_of_seg.data(), nseg, MFX_HOST, st));
+    MFX_TRY(seg_of_rank_.alloc(L.nne ? L.nne : 1));
+    MFX_TRY(seg_of_rank_.upload(L.seg_of_rank.data(), L.nne, MFX_HOST, st));
+    MFX_TRY(span_rank_base_.alloc(L.nspans));
+    MFX_TRY(span_rank_base_.upload(L.span_rank_base.data(), L.nspans, MFX_HOST, st));
+    MFX_TRY(gpart_.alloc_zero(L.nne ? L.nne : 1, st));
+    MFX_TRY(hpart_.alloc_zero(L.nne ? L.nne : 1, st));
+    MFX_TRY(carry_g_.alloc_zero(L.nspans, st));
+    MFX_TRY(carry_h_.alloc_zero(L.nspans, st));
+    // the host vectors behind the async uploads must outlive the copies
+    MFX_HIP(hipStreamSynchronize(st));
+
+    view.nseg = nseg; view.nne = L.nne; view.nnz = nnz; view.nspans = L.nspans;
+    view.tiles_per_span = L.tiles_per_span;
+    view.ptr = ptr_.get(); view.idx = idx_.get(); view.val = val_.get(); view.flags = flags_.get();
+    view.rank_of_seg = rank_of_seg_.get(); view.seg_of_rank = seg_of_rank_.get();
+    view.span_rank_base = span_rank_base_.get(); view.gpart = gpart_.get(); view.hpart = hpart_.get();
+    view.carry_g = carry_g_.get(); view.carry_h = carry_h_.get();
+    // the big host-side flag vector is no longer needed
+    layout_.flags.clear(); layout_.flags.shrink_to_fit();
+    return MFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static const char* kKernelNames[KernelProfiler::K_COUNT] = {
+    "ccd_fused_csc_pass", "ccd_fused_csr_pass", "ccd_flat_sweep", "ccd_flat_resid", "ccd_finalize",
+    "ccd_combine_dense", "ccd_pack", "test_rmse", "rccl_allreduce", "ccd_wave_sweep", "ccd_wave_resid"};
+
+const char* KernelProfiler::name(int id) { return id >= 0 && id < K_COUNT ? kKernelNames[id] : "?"; }
+
+KernelProfiler::~KernelProfiler() {
+    for (hipEvent_t e : pool_) (void) hipEventDestroy(e);
+}
+
+int KernelProfiler::take(hipEvent_t* e) {
+    if (used_ == pool_.size()) {
+        hipEvent_t n;
+        MFX_HIP(hipEventCreate(&n));
+        pool_.push_back(n);
+    }
+    *e = pool_[used_++];
+    return MFX_OK;
+}
+
+int KernelProfiler::begin(int id, hipStream_t st) {
+    if (!on_) return MFX_OK;
+    Rec r;
+    r.id = id;
+    MFX_TRY(take(&r.a));
+    MFX_TRY(take(&r.b));
+    MFX_HIP(hipEventRecord(r.a, st));
+    recs_.push_back(r);
+    return MFX_OK;
+}
+
+int KernelProfiler::end(hipStream_t st) {
+    if (!on_) return MFX_OK;
+    MFX_HIP(hipEventRecord(recs_.back().b, st));
+    return MFX_OK;
+}
+
+int KernelProfiler::collect() {
+    for (const Rec& r : recs_) {
+        float ms = 0.f;
+        MFX_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        seconds[r.id] += ms * 1e-3;
+        launches[r.id] += 1;
+    }
+    recs_.clear();
+    used_ = 0;
+    return MFX_OK;
+}
+
+void KernelProfiler::reset_totals() {
+    for (int i = 0; i < K_COUNT; ++i) { seconds[i] = 0; launches[i] = 0; }
+}
+
+#define PROF(id, call)                    \
+    do {                                  \
+        MFX_TRY(prof_.begin((id), st_));  \
+        MFX_TRY(call);                    \
+        MFX_TRY(prof_.end(st_));          \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+int CcdSolver::create(CcdSolver** out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
+                      mfx_memspace space, const mfx_shard* shard) {
+    MFX_REQUIRE(out && R && p, "mfx_ccd_create: null argument");
+    std::unique_ptr<CcdSolver> s(new CcdSolver());
+    MFX_TRY(s->init(R, T, p, space, shard));
+    *out = s.release();
+    return MFX_OK;
+}
+
+CcdSolver::~CcdSolver() {
+    (void) hipSetDevice(device_);
+    for (hipEvent_t& e : ev_)
+        if (e) (void) hipEventDestroy(e);
+    if (st_) {
+        (void) hipStreamSynchronize(st_);
+        (void) hipStreamDestroy(st_);
+    }
+}
+
+int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space,
+                    const mfx_shard* shard) {
+    MFX_REQUIRE(R->rows > 0 && R->cols > 0 && R->nnz >= 0, "bad matrix shape %lld x %lld, nnz %lld",
+                (long long) R->rows, (long long) R->cols, (long long) R->nnz);
+    MFX_REQUIRE(R->rows < (int64_t) 0xFFFFFFFFll && R->cols < (int64_t) 0xFFFFFFFFll &&
+                    R->nnz < (int64_t) 0xFFFF0000ll, "matrix exceeds 32-bit index range");
+    MFX_REQUIRE(p->k >= 1, "k must be >= 1");
+    MFX_REQUIRE(p->maxinneriter >= 1, "maxinneriter must be >= 1");
+    MFX_REQUIRE(R->nnz == 0 || (R->csc_col_ptr && R->csc_row_idx && R->csc_val && R->csr_row_ptr &&
+                                R->csr_col_idx && R->csr_val), "null CSR/CSC array");
+    p_ = *p;
+    device_ = p->device;
+    MFX_TRY(use_device(device_));
+    MFX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    for (hipEvent_t& e : ev_) MFX_HIP(hipEventCreate(&e));
+    m_ = (uint32_t) R->rows; n_ = (uint32_t) R->cols; k_ = p->k; nnz_ = (uint64_t) R->nnz;
+    prof_.enable(p->profile != 0 || p->schedule == 0);
+
+    const uint32_t tps = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : 0;
+    MFX_TRY(csc_.build(n_, nnz_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, tps, st_));
+    MFX_TRY(csr_.build(m_, nnz_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, tps, st_));
+
+    MFX_TRY(W_.alloc_zero((size_t) k_ * m_, st_));
+    MFX_TRY(H_.alloc_zero((size_t) k_ * n_, st_));
+    MFX_TRY(packA_.alloc_zero(m_, st_));
+    MFX_TRY(packB_.alloc_zero(n_, st_));
+    MFX_TRY(packC_.alloc_zero(n_, st_));
+    MFX_TRY(gh_cols_.alloc_zero((size_t) 2 * n_, st_));
+    MFX_TRY(gh_rows_.alloc_zero((size_t) 2 * m_, st_));
+
+    if (shard && shard->comm) {
+        MFX_REQUIRE(shard->global_col_nnz, "sharded solve needs global_col_nnz");
+        comm_ = shard->comm;
+        MFX_TRY(global_col_nnz_.alloc(n_));
+        MFX_TRY(global_col_nnz_.upload(shard->global_col_nnz, n_, space, st_));
+        global_test_nnz_ = shard->global_test_nnz;
+    }
+    nnz_test_ = T ? T->nnz : 0;
+    if (!comm_) global_test_nnz_ = nnz_test_;
+    if (nnz_test_ > 0) {
+        MFX_REQUIRE(T->row && T->col && T->val, "null test array");
+        MFX_TRY(t_row_.alloc(nnz_test_)); MFX_TRY(t_row_.upload(T->row, nnz_test_, space, st_));
+        MFX_TRY(t_col_.alloc(nnz_test_)); MFX_TRY(t_col_.upload(T->col, nnz_test_, space, st_));
+        MFX_TRY(t_val_.alloc(nnz_test_)); MFX_TRY(t_val_.upload(T->val, nnz_test_, space, st_));
+    }
+    MFX_TRY(rmse_partials_.alloc_zero(kRmseBlocks, st_));
+    MFX_TRY(rmse_sum_.alloc_zero(1, st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    return MFX_OK;
+}
+
+int CcdSolver::set_factors(const float* W, const float* H, mfx_memspace space) {
+    MFX_REQUIRE(W, "mfx_ccd_set_factors: W is required");
+    MFX_REQUIRE(oiter_ == 0, "factors can only be set before the first iteration");
+    // CCD++ starts from H = 0 with the residual equal to R (src/CCD.cpp:55-60, CCD_CUDA.cu:287);
+    // a non-zero H would need the residual rebuilt, which the reference never does either.
+    MFX_REQUIRE(H == nullptr, "mfx_ccd_set_factors: H must be NULL (CCD++ starts from H = 0)");
+    MFX_TRY(use_device(device_));
+    MFX_TRY(W_.upload(W, (size_t) k_ * m_, space, st_));
+    MFX_HIP(hipMemsetAsync(H_.get(), 0, sizeof(float) * (size_t) k_ * n_, st_));
+    MFX_TRY(launch_pack2(m_, nullptr, Wt(0), packA_.get(), st_));
+    MFX_TRY(launch_pack2(n_, nullptr, Ht(0), packB_.get(), st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    pending_sub_ = -1;
+    factors_set_ = true;
+    return MFX_OK;
+}
+
+// (g,h) of the column side are partial sums over this shard's rows: all-reduce before dividing.
+int CcdSolver::finalize_cols(const FinalizeArgs& base) {
+    FinalizeArgs f = base;
+    if (comm_) {
+        PROF(KernelProfiler::K_COMBINE, launch_combine_dense(csc_.view, gh_cols_.get(), st_));
+        PROF(KernelProfiler::K_ALLREDUCE, comm_allreduce_f32(comm_, gh_cols_.get(), (size_t) 2 * n_, st_));
+        f.gh_dense = gh_cols_.get();
+        f.cnt_override = global_col_nnz_.get();
+    }
+    PROF(KernelProfiler::K_FINALIZE, launch_finalize(csc_.view, f, st_));
+    return MFX_OK;
+}
+
+int CcdSolver::rank_fused(uint32_t t) {
+    const uint32_t next = (t + 1) % k_;
+    // invariant on entry: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old)
+    PROF(KernelProfiler::K_FCSC, launch_flat(FM_FCSC, csc_.view, packA_.get(), packB_.get(), 0, st_));
+    FinalizeArgs fv;
+    fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next);
+    fv.pack4 = packC_.get();
+    MFX_TRY(finalize_cols(fv));
+    // per-row scalars of the CSR pass are exactly packA (u_prev_new, u_t_old), indexed by row
+    PROF(KernelProfiler::K_FCSR, launch_flat(FM_FCSR, csr_.view, packC_.get(), packA_.get(), 0, st_));
+    FinalizeArgs fu;
+    fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
+    PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, fu, st_));
+
+    for (int it = 2; it <= p_.maxinneriter; ++it) {  // remaining inner iterations: read-only sweeps
+        PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csc_.view, Wt(t), nullptr, 0, st_));
+        FinalizeArgs f2; f2.lambda = p_.lambda; f2.out_vec = Ht(t);
+        MFX_TRY(finalize_cols(f2));
+        PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csr_.view, Ht(t), nullptr, 0, st_));
+        FinalizeArgs f3; f3.lambda = p_.lambda; f3.out_vec = Wt(t);
+        PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, f3, st_));
+    }
+    if (p_.maxinneriter > 1) {  // the packs must carry the FINAL (u_t, v_t)
+        PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(t), Wt(next), packA_.get(), st_));
+        PROF(KernelProfiler::K_PACK, launch_pack2(n_, Ht(t), Ht(next), packB_.get(), st_));
+    }
+    pending_sub_ = (int32_t) t;
+    return MFX_OK;
+}
+
+int CcdSolver::flush_pending() {
+    if (pending_sub_ < 0) return MFX_OK;
+    const uint32_t t = (uint32_t) pending_sub_, next = (t + 1) % k_;
+    PROF(KernelProfiler::K_RESID, launch_flat(FM_RESID, csc_.view, Wt(t), Ht(t), 0, st_));
+    PROF(KernelProfiler::K_RESID, launch_flat(FM_RESID, csr_.view, Ht(t), Wt(t), 0, st_));
+    PROF(KernelProfiler::K_PACK, launch_pack2(m_, nullptr, Wt(next), packA_.get(), st_));
+    PROF(KernelProfiler::K_PACK, launch_pack2(n_, nullptr, Ht(next), packB_.get(), st_));
+    pending_sub_ = -1;
+    return MFX_OK;
+}
+
+int CcdSolver::sweep(SegStreamStore& s, const float* vec, float* out, bool is_col_side) {
+    FinalizeArgs f;
+    f.lambda = p_.lambda;
+    f.out_vec = out;
+    if (p_.kernel_variant == 0) {
+        float* gh = is_col_side ? gh_cols_.get() : gh_rows_.get();
+        PROF(KernelProfiler::K_SWEEP_WAVE, launch_sweep_wave(s.view, vec, gh, gh + s.view.nseg, st_));
+        f.gh_dense = gh;
+        if (is_col_side && comm_) {
+            PROF(KernelProfiler::K_ALLREDUCE, comm_allreduce_f32(comm_, gh, (size_t) 2 * n_, st_));
+            f.cnt_override = global_col_nnz_.get();
+        }
+        PROF(KernelProfiler::K_FINALIZE, launch_finalize(s.view, f, st_));
+    } else {
+        PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, s.view, vec, nullptr, 0, st_));
+        if (is_col_side) MFX_TRY(finalize_cols(f));
+        else PROF(KernelProfiler::K_FINALIZE, launch_finalize(s.view, f, st_));
+    }
+    return MFX_OK;
+}
+
+int CcdSolver::resid(SegStreamStore& s, const float* gathered, const float* per_seg, int add) {
+    if (p_.kernel_variant == 0)
+        PROF(KernelProfiler::K_RESID_WAVE, launch_resid_wave(s.view, gathered, per_seg, add, st_));
+    else
+        PROF(KernelProfiler::K_RESID, launch_flat(FM_RESID, s.view, gathered, per_seg, add, st_));
+    return MFX_OK;
+}
+
+// The reference's kernel sequence, one launch per reference kernel (cuda_src/CCD_CUDA.cu:349-377).
+int CcdSolver::rank_as_written(uint32_t t, bool add_back) {
+    float* u = Wt(t);
+    float* v = Ht(t);
+    if (add_back) {
+        MFX_TRY(resid(csc_, u, v, 1));
+        MFX_TRY(resid(csr_, v, u, 1));
+    }
+    for (int it = 1; it <= p_.maxinneriter; ++it) {
+        MFX_TRY(sweep(csc_, u, v, true));   // v <- rank-one over columns, using u
+        MFX_TRY(sweep(csr_, v, u, false));  // u <- rank-one over rows, using the new v
+    }
+    MFX_TRY(resid(csc_, u, v, 0));
+    MFX_TRY(resid(csr_, v, u, 0));
+    return MFX_OK;
+}
+
+int CcdSolver::test_rmse(double* rmse_out) {
+    *rmse_out = 0.0;
+    if (global_test_nnz_ <= 0) return MFX_OK;
+    if (nnz_test_ > 0) {
+        PROF(KernelProfiler::K_RMSE,
+             launch_test_sqerr(nnz_test_, t_row_.get(), t_col_.get(), t_val_.get(), W_.get(), H_.get(), m_, n_, k_,
+                               0, rmse_partials_.get(), kRmseBlocks, rmse_sum_.get(), st_));
+    } else {
+        MFX_HIP(hipMemsetAsync(rmse_sum_.get(), 0, sizeof(double), st_));
+    }
+    if (comm_) PROF(KernelProfiler::K_ALLREDUCE, comm_allreduce_f64(comm_, rmse_sum_.get(), 1, st_));
+    double sum = 0.0;
+    MFX_HIP(hipMemcpyAsync(&sum, rmse_sum_.get(), sizeof(double), hipMemcpyDeviceToHost, st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    *rmse_out = std::sqrt(sum / (double) global_test_nnz_);
+    return MFX_OK;
+}
+
+int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
+    MFX_REQUIRE(n_outer >= 0, "n_outer must be >= 0");
+    MFX_REQUIRE(factors_set_, "mfx_ccd_iterate: call mfx_ccd_set_factors first");
+    MFX_TRY(use_device(device_));
+    for (int it = 0; it < n_outer; ++it) {
+        const int64_t oiter = oiter_ + 1;
+        double before[KernelProfiler::K_COUNT];
+        for (int i = 0; i < KernelProfiler::K_COUNT; ++i) before[i] = prof_.seconds[i];
+        MFX_HIP(hipEventRecord(ev_[0], st_));
+        for (uint32_t t = 0; t < k_; ++t) {
+            if (p_.schedule == 0) MFX_TRY(rank_as_written(t, oiter > 1));
+            else MFX_TRY(rank_fused(t));
+        }
+        MFX_HIP(hipEventRecord(ev_[1], st_));
+        double rmse = 0.0;
+        MFX_HIP(hipEventRecord(ev_[2], st_));
+        if (with_rmse) MFX_TRY(test_rmse(&rmse));
+        MFX_HIP(hipEventRecord(ev_[3], st_));
+        MFX_HIP(hipStreamSynchronize(st_));
+        MFX_TRY(prof_.collect());
+        float ms_iter = 0.f, ms_rmse = 0.f;
+        MFX_HIP(hipEventElapsedTime(&ms_iter, ev_[0], ev_[1]));
+        MFX_HIP(hipEventElapsedTime(&ms_rmse, ev_[2], ev_[3]));
+        mfx_iter_report rep;
+        if (p_.schedule == 0) {  // the reference's split: sweeps vs residual updates
+            auto d = [&](int id) { return prof_.seconds[id] - before[id]; };
+            rep.update_time = d(KernelProfiler::K_RESID) + d(KernelProfiler::K_RESID_WAVE);
+            rep.rank_time = ms_iter * 1e-3 - rep.update_time;
+        } else {  // fused passes do both at once: everything is booked as rank_time
+            rep.rank_time = ms_iter * 1e-3;
+            rep.update_time = 0.0;
+        }
+        rep.rmse = rmse;
+        rep.rmse_time = ms_rmse * 1e-3;
+        rank_acc_ += rep.rank_time;
+        update_acc_ += rep.update_time;
+        oiter_ = oiter;
+        if (reports) reports[it] = rep;
+        if (p_.verbose && (!comm_ || comm_->rank == 0)) {
+            // log line format of cuda_src/CCD_CUDA.cu:405-406
+            printf("[-INFO-] iteration num %d \trank_time %.4lf|%.4lf s \tupdate_time %.4lf|%.4lfs \tRMSE=%lf time:%fs\n",
+                   (int) oiter, rep.rank_time, rank_acc_, rep.update_time, update_acc_, rep.rmse, rep.rmse_time);
+            fflush(stdout);
+        }
+    }
+    if (!p_.profile) prof_.reset_totals();
+    return MFX_OK;
+}
+
+int CcdSolver::set_profile(bool on) {
+    MFX_REQUIRE(p_.schedule != 0 || on, "schedule 0 derives its rank/update split from the launch events");
+    p_.profile = on ? 1 : 0;
+    prof_.enable(on || p_.schedule == 0);
+    prof_.reset_totals();
+    return MFX_OK;
+}
+
+int CcdSolver::get_factors(float* W, float* H, mfx_memspace space) {
+    MFX_TRY(use_device(device_));
+    const hipMemcpyKind kind = space == MFX_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (W) MFX_HIP(hipMemcpyAsync(W, W_.get(), sizeof(float) * (size_t) k_ * m_, kind, st_));
+    if (H) MFX_HIP(hipMemcpyAsync(H, H_.get(), sizeof(float) * (size_t) k_ * n_, kind, st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    return MFX_OK;
+}
+
+int CcdSolver::get_residual(float* csc_val, float* csr_val) {
+    MFX_TRY(use_device(device_));
+    MFX_TRY(flush_pending());
+    if (csc_val && nnz_) MFX_HIP(hipMemcpyAsync(csc_val, csc_.view.val, sizeof(float) * nnz_, hipMemcpyDeviceToHost, st_));
+    if (csr_val && nnz_) MFX_HIP(hipMemcpyAsync(csr_val, csr_.view.val, sizeof(float) * nnz_, hipMemcpyDeviceToHost, st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    MFX_TRY(prof_.collect());
+    return MFX_OK;
+}
+
+}  // namespace mfx

@@ -1,0 +1,117 @@
+// ccd_solver.hpp -- resident CCD++ solver: device state + the outer/rank/inner loop of
+// ccdpp_NV (cuda_src/CCD_CUDA.cu:224-451) re-designed for MI355X: everything stream-ordered,
+// no per-launch host sync, fused passes by default (see DESIGN.md "CCD++ schedule").
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ccd_kernels.hpp"
+#include "comm.hpp"
+#include "flat_layout.hpp"
+
+namespace mfx {
+
+// Owns one orientation's device arrays; `view` is what the kernels see.
+class SegStreamStore {
+public:
+    // ptr/idx/val live in `space`.  val may be nullptr (zeros).  tiles_per_span 0 = auto.
+    int build(uint32_t nseg, uint64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
+              mfx_memspace space, uint32_t tiles_per_span, hipStream_t st);
+    SegStreamDev view;
+    const FlatLayoutHost& layout() const { return layout_; }
+
+private:
+    FlatLayoutHost layout_;
+    DevBuf<uint32_t> ptr_, idx_, seg_of_rank_, span_rank_base_;
+    DevBuf<float> val_, gpart_, hpart_, carry_g_, carry_h_;
+    DevBuf<uint64_t> flags_;
+    DevBuf<int32_t> rank_of_seg_;
+};
+
+// Optional per-launch HIP-event bracketing (mfx_params.profile).  Events are recorded on the
+// solver's own stream -- the stream the kernels run on.
+class KernelProfiler {
+public:
+    ~KernelProfiler();
+    void enable(bool on) { on_ = on; }
+    bool enabled() const { return on_; }
+    int begin(int name_id, hipStream_t st);
+    int end(hipStream_t st);
+    int collect();  // after a stream sync: fold elapsed times into the per-name totals
+    void reset_totals();
+    static const char* name(int id);
+    enum { K_FCSC = 0, K_FCSR, K_SWEEP, K_RESID, K_FINALIZE, K_COMBINE, K_PACK, K_RMSE, K_ALLREDUCE,
+           K_SWEEP_WAVE, K_RESID_WAVE, K_COUNT };
+    double seconds[K_COUNT] = {};
+    int64_t launches[K_COUNT] = {};
+
+private:
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs_;
+    std::vector<hipEvent_t> pool_;
+    size_t used_ = 0;
+    bool on_ = false;
+    int take(hipEvent_t* e);
+};
+
+class CcdSolver {
+public:
+    static int create(CcdSolver** out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
+                      mfx_memspace space, const mfx_shard* shard);
+    ~CcdSolver();
+    int set_factors(const float* W, const float* H, mfx_memspace space);
+    int iterate(int n_outer, int with_rmse, mfx_iter_report* reports);
+    int get_factors(float* W, float* H, mfx_memspace space);
+    int get_residual(float* csc_val, float* csr_val);
+    KernelProfiler& profiler() { return prof_; }
+    int set_profile(bool on);
+
+private:
+    CcdSolver() = default;
+    int init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space,
+             const mfx_shard* shard);
+    int rank_fused(uint32_t t);
+    int rank_as_written(uint32_t t, bool add_back);
+    int flush_pending();
+    int sweep(SegStreamStore& s, const float* vec, float* out, bool is_col_side);
+    int resid(SegStreamStore& s, const float* gathered, const float* per_seg, int add);
+    int finalize_cols(const FinalizeArgs& base);  // CSC side: all-reduce across shards if sharded
+    int test_rmse(double* rmse_out);
+    float* Wt(uint32_t t) { return W_.get() + (size_t) t * m_; }
+    float* Ht(uint32_t t) { return H_.get() + (size_t) t * n_; }
+
+    int device_ = 0;
+    hipStream_t st_ = nullptr;
+    mfx_params p_{};
+    uint32_t m_ = 0, n_ = 0, k_ = 0;
+    uint64_t nnz_ = 0;
+    SegStreamStore csc_, csr_;
+    DevBuf<float> W_, H_;
+    DevBuf<float2> packA_, packB_;  // [m], [n]
+    DevBuf<float4> packC_;          // [n]
+    DevBuf<float> gh_cols_, gh_rows_;  // dense (g,h): [2n], [2m]
+    // multi-GPU
+    mfx_comm_s* comm_ = nullptr;
+    DevBuf<uint32_t> global_col_nnz_;
+    int64_t global_test_nnz_ = 0;
+    // test set
+    int64_t nnz_test_ = 0;
+    DevBuf<uint32_t> t_row_, t_col_;
+    DevBuf<float> t_val_;
+    DevBuf<double> rmse_partials_, rmse_sum_;
+    // state
+    int64_t oiter_ = 0;        // outer iterations completed
+    double rank_acc_ = 0, update_acc_ = 0;  // running totals for the reference's log line
+    int32_t pending_sub_ = -1; // fused schedule: rank whose new (u,v) is not yet subtracted
+    bool factors_set_ = false;
+    KernelProfiler prof_;
+    hipEvent_t ev_[6] = {};
+};
+
+}  // namespace mfx
+
+struct mfx_ccd_s {
+    mfx::CcdSolver* impl;
+};

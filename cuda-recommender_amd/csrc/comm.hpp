@@ -1,0 +1,22 @@
+// comm.hpp -- thin communicator over RCCL (librccl is dlopen'ed on first use so that a
+// single-GPU process never loads it).  One process per GPU; collectives are enqueued on the
+// solver's stream, no host synchronisation on the data path.
+#pragma once
+
+#include "common.hpp"
+
+struct mfx_comm_s {
+    void* nccl = nullptr;  // ncclComm_t
+    int rank = 0;
+    int nranks = 1;
+    int device = 0;
+};
+
+namespace mfx {
+int comm_unique_id(void* id_out);
+int comm_create(mfx_comm_s** out, const void* id, int rank, int nranks, int device);
+int comm_destroy(mfx_comm_s* c);
+// In-place sum all-reduce on `st`.
+int comm_allreduce_f32(mfx_comm_s* c, float* buf, size_t count, hipStream_t st);
+int comm_allreduce_f64(mfx_comm_s* c, double* buf, size_t count, hipStream_t st);
+}  // namespace mfx

@@ -1,0 +1,115 @@
+"""ctypes binding of libmfx.so (include/mfx.h).  The library is the product; this file only
+declares its C ABI.  Loading fails loudly when the shared object is missing -- there is no
+Python or CPU fallback for any compute entry point."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libmfx.so")
+
+MFX_HOST, MFX_DEVICE = 0, 1
+MFX_COMM_ID_BYTES = 128
+
+u32p = C.POINTER(C.c_uint32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+i64p = C.POINTER(C.c_int64)
+
+
+class mfx_csx(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("nnz", C.c_int64),
+                ("csc_col_ptr", C.c_void_p), ("csc_row_idx", C.c_void_p), ("csc_val", C.c_void_p),
+                ("csr_row_ptr", C.c_void_p), ("csr_col_idx", C.c_void_p), ("csr_val", C.c_void_p)]
+
+
+class mfx_coo(C.Structure):
+    _fields_ = [("nnz", C.c_int64), ("row", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p)]
+
+
+class mfx_params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("lambda_", C.c_float), ("maxiter", C.c_int32), ("maxinneriter", C.c_int32),
+                ("nBlocks", C.c_uint32), ("nThreadsPerBlock", C.c_uint32), ("verbose", C.c_int32),
+                ("device", C.c_int32), ("schedule", C.c_int32), ("kernel_variant", C.c_int32),
+                ("profile", C.c_int32), ("tiles_per_span", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class mfx_iter_report(C.Structure):
+    _fields_ = [("rank_time", C.c_double), ("update_time", C.c_double), ("rmse", C.c_double),
+                ("rmse_time", C.c_double)]
+
+
+class mfx_shard(C.Structure):
+    _fields_ = [("comm", C.c_void_p), ("global_col_nnz", C.c_void_p), ("global_test_nnz", C.c_int64)]
+
+
+class MfxError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); every symbol include/mfx.h declares
+SIGNATURES = {
+    "mfx_last_error": (C.c_char_p, []),
+    "mfx_version": (C.c_int, []),
+    "mfx_device_count": (C.c_int, []),
+    "mfx_params_default": (None, [C.POINTER(mfx_params)]),
+    "mfx_ccdpp_run": (C.c_int, [C.POINTER(mfx_csx), C.POINTER(mfx_coo), C.c_void_p, C.c_void_p,
+                                C.POINTER(mfx_params), C.POINTER(mfx_iter_report)]),
+    "mfx_als_run": (C.c_int, [C.POINTER(mfx_csx), C.POINTER(mfx_coo), C.c_void_p, C.c_void_p,
+                              C.POINTER(mfx_params), C.POINTER(mfx_iter_report)]),
+    "mfx_ccd_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(mfx_csx), C.POINTER(mfx_coo),
+                                 C.POINTER(mfx_params), C.c_int, C.POINTER(mfx_shard)]),
+    "mfx_ccd_set_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mfx_ccd_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(mfx_iter_report)]),
+    "mfx_ccd_get_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mfx_ccd_get_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfx_ccd_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), f64p, i64p]),
+    "mfx_ccd_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "mfx_ccd_destroy": (C.c_int, [C.c_void_p]),
+    "mfx_als_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(mfx_csx), C.POINTER(mfx_coo),
+                                 C.POINTER(mfx_params), C.c_int]),
+    "mfx_als_set_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mfx_als_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(mfx_iter_report)]),
+    "mfx_als_get_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mfx_als_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), f64p, i64p]),
+    "mfx_als_destroy": (C.c_int, [C.c_void_p]),
+    "mfx_rank_one_sweep": (C.c_int, [C.c_int64, C.c_int64, u32p, u32p, f32p, C.c_int64, f32p, C.c_float, f32p,
+                                     C.c_int, C.c_int]),
+    "mfx_update_rating": (C.c_int, [C.c_int64, C.c_int64, u32p, u32p, f32p, C.c_int64, f32p, f32p, C.c_int,
+                                    C.c_int, C.c_int]),
+    "mfx_test_rmse": (C.c_int, [C.POINTER(mfx_coo), f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int, f64p,
+                                C.c_int]),
+    "mfx_als_gramian": (C.c_int, [C.c_int64, u32p, C.c_int64, f32p, C.c_int64, f32p, C.c_int]),
+    "mfx_als_half": (C.c_int, [C.c_int64, C.c_int64, u32p, u32p, f32p, C.c_int64, f32p, f32p, C.c_int64,
+                               C.c_float, C.c_int]),
+    "mfx_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mfx_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mfx_comm_rank": (C.c_int, [C.c_void_p]),
+    "mfx_comm_size": (C.c_int, [C.c_void_p]),
+    "mfx_comm_destroy": (C.c_int, [C.c_void_p]),
+    "mfx_initial_col": (None, [f32p, C.c_int64, C.c_int64]),
+    "mfx_partition_rows": (C.c_int, [C.c_int64, u32p, C.c_int, i64p]),
+    "mfx_extract_shard": (C.c_int, [C.POINTER(mfx_csx), C.c_int64, C.c_int64, u32p, u32p, f32p, u32p, u32p, f32p]),
+}
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfxError(f"{LIB_PATH} is missing: build it with `make -C {_PKG} lib` "
+                           "(or __graft_entry__.build()); there is no fallback path")
+        _LIB = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_LIB, name)  # AttributeError here == the .so does not export the ABI
+            fn.restype = res
+            fn.argtypes = args
+    return _LIB
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise MfxError(f"libmfx error {rc}: {lib().mfx_last_error().decode(errors='replace')}")

@@ -79,7 +79,10 @@ typedef struct mfx_params {
     int32_t schedule;          /* CCD++ kernel schedule: 0 = as written (separate add-back,
                                   sweeps, subtract launches, one per reference kernel),
                                   1 = fused passes (default; same arithmetic, fewer bytes) */
-    int32_t reserved[7];
+    int32_t kernel_variant;    /* schedule 0 only: 0 = wave-per-segment kernels, 1 = flat-stream */
+    int32_t profile;           /* 1: bracket every launch with HIP events (mfx_*_kernel_times) */
+    int32_t tiles_per_span;    /* flat-stream span length / 256; 0 = choose from nnz */
+    int32_t reserved[4];
 } mfx_params;
 
 /* One outer iteration's numbers == the fields of the reference's log line
@@ -145,6 +148,8 @@ int mfx_ccd_get_residual(mfx_ccd_t s, float* csc_val, float* csr_val);
  * solver's stream: names[i] / seconds[i] / launches[i] for i < returned count (<= cap). */
 int mfx_ccd_kernel_times(mfx_ccd_t s, int cap, const char** names, double* seconds,
                          int64_t* launches);
+/* Turns the per-launch event bracketing (mfx_params.profile) on or off between iterate calls. */
+int mfx_ccd_set_profile(mfx_ccd_t s, int on);
 int mfx_ccd_destroy(mfx_ccd_t s);
 
 int mfx_als_create(mfx_als_t* out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
@@ -199,6 +204,11 @@ int mfx_comm_destroy(mfx_comm_t c);
 /* ------------------------------------------------------------------------------------
  * Host-side helpers on the path (no GPU needed).
  * ---------------------------------------------------------------------------------- */
+/* initial_col (src/tools.cpp:165-173): X flat [k][n], srand(0) then glibc rand() consumed
+ * with i (0..n) outer and j (0..k) inner: X[j*n+i] = 0.1f*(float(rand())/RAND_MAX)+0.001f.
+ * CCD++ calls it as (W, k, rows)/(H, k, cols); ALS as (W, rows, k)/(H, cols, k)
+ * (src/main.cpp:86-98). */
+void mfx_initial_col(float* X, int64_t k, int64_t n);
 /* nnz-balanced contiguous row-block partition: bounds[g] .. bounds[g+1] are shard g's rows
  * (prefix sums of csr_row_ptr, SURVEY.md 8e "Partition").  bounds has nshards+1 entries. */
 int mfx_partition_rows(int64_t rows, const uint32_t* csr_row_ptr, int nshards, int64_t* bounds);

@@ -1,0 +1,102 @@
+"""GPU parity tests for the ALS path (MFMA Gramian + LDS Cholesky) through the C ABI.
+
+Tolerance: the Gramian is an exact-fp32 MFMA chain (differs from the CPU's unfused sums by
+rounding only: 1e-5 relative-to-scale); the solve uses L z = b, L^T y = z instead of the
+reference's explicit inverse, so factors agree to 5e-3 relative-to-scale after 3 iterations on
+these (deliberately ill-conditioned, tiny) systems and test RMSE to 1e-4.
+"""
+import numpy as np
+import pytest
+
+from conftest import CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mfx():
+    import mfx as m
+    assert m.device_count() >= 1
+    return m
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) / max(1e-30, float(np.max(np.abs(b))))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_gramian_golden(mfx, name):
+    g, d = load_golden(name)
+    k = int(g["k"][0]); row = int(g["step_als_row"][0])
+    lo, hi = int(d.csr_row_ptr[row]), int(d.csr_row_ptr[row + 1])
+    A = mfx.als_gramian(np.ascontiguousarray(d.csr_col_idx[lo:hi]), np.ascontiguousarray(g["als__H0"]), k)
+    assert relerr(A, g["step_gram"]) < 1e-5
+    assert np.array_equal(A, A.T)
+
+
+@pytest.mark.parametrize("k", [5, 32, 40, 64, 100, 128])
+def test_gramian_all_tile_counts(mfx, orc, k):
+    rng = np.random.default_rng(k)
+    X = rng.standard_normal((300, k)).astype(np.float32)
+    idx = rng.integers(0, 300, 777).astype(np.uint32)
+    A = mfx.als_gramian(idx, X, k)
+    assert relerr(A, orc.gramian(idx, X, k)) < 2e-5
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_als_half_golden_first_half(mfx, orc, name):
+    g, d = load_golden(name)
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    H0 = np.ascontiguousarray(g["als__H0"])
+    W1 = mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, k, lam)
+    ref = orc.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, k, lam, 2)
+    assert relerr(W1, ref) < 5e-3
+    empty = np.diff(d.csr_row_ptr.astype(np.int64)) == 0
+    assert np.all(W1[empty] == 0)  # zero-row rule (src/ALS.cpp:151-157)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_als_matches_reference_golden(mfx, name):
+    g, d = load_golden(name)
+    k, lam, t = int(g["k"][0]), float(g["lam"][0]), int(g["als__maxiter"][0])
+    p = mfx.parameter(); p.k, p.lambda_, p.maxiter = k, lam, t
+    W = np.zeros((d.rows, k), np.float32)
+    H = np.array(g["als__H0"], np.float32, copy=True)
+    reports = mfx.kernel_wrapper_als_NV(d, mfx.test_data_of(d), W, H, p)
+    assert mfx.kernel_wrapper_als_NV.last_status == 0
+    rmse = np.array([r.rmse for r in reports])
+    assert np.all(np.abs(rmse - g["als__rmse"]) < 1e-4), (rmse, g["als__rmse"])
+    assert relerr(W, g["als__W"]) < 5e-3 and relerr(H, g["als__H"]) < 5e-3
+
+
+@pytest.mark.parametrize("k", [10, 40, 64, 128])
+def test_als_medium_vs_oracle(mfx, orc, k):
+    """Rows longer than one chunk (split Gramians + reducer), k across all tile counts."""
+    d = mfx.dataset.synth_ratings(3000, 400, 150_000, seed=31 + k, skew=1.1, test_frac=0.01, empty_row_frac=0.02)
+    assert np.diff(d.csc_col_ptr.astype(np.int64)).max() > 1024
+    H0 = mfx.initial_col(d.cols, k)
+    Wr, Hr, rmse_ref, _ = orc.als(d, H0, k, 0.05, 2, orc.max_threads())
+    s = mfx.AlsSolver(d, mfx.test_data_of(d), _p(mfx, k, 0.05, 2))
+    s.set_factors(H0.copy())
+    rep = s.iterate(2)
+    W, H = s.get_factors()
+    s.close()
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-4)
+    assert relerr(W, Wr) < 5e-3 and relerr(H, Hr) < 5e-3
+
+
+def _p(mfx, k, lam, t):
+    p = mfx.parameter(); p.k, p.lambda_, p.maxiter = k, lam, t
+    return p
+
+
+def test_als_rank_limit_is_an_error(mfx):
+    d = mfx.dataset.synth_ratings(100, 80, 1000, seed=2)
+    with pytest.raises(mfx.MfxError, match="not supported"):
+        mfx.AlsSolver(d, None, _p(mfx, 129, 0.1, 1))

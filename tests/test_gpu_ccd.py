@@ -1,0 +1,234 @@
+"""GPU parity tests for the CCD++ hot path: every call goes through libmfx.so's C ABI and is
+checked against the CPU oracle (itself pinned bit-exact to the reference by
+test_oracle_pinned.py) and against the committed golden vectors.
+
+Tolerances (fp32): the residual update is elementwise and must be BIT-EXACT; anything that sums
+over a row/column differs from the CPU only by summation order, bounded per sweep by
+~len * 2^-24 relative -- 2e-5 is asserted; whole solves amplify that over k*iters updates, so
+factors are compared at 2e-3 relative-to-scale and test RMSE at the north-star's 1e-4.
+"""
+import numpy as np
+import pytest
+
+from conftest import CASES, bits, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mfx():
+    import mfx as m
+    assert m.device_count() >= 1, "no HIP device: these tests must run on the GPU box"
+    return m
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def medium(mfx):
+    # ML-1M shaped (BASELINE.json configs[1]): 6040 x 3706, Z = 1e6, some empty rows/cols
+    return mfx.dataset.synth_ratings(6040, 3706, 1_000_000, seed=7, skew=0.9, test_frac=0.01,
+                                     empty_row_frac=0.01, empty_col_frac=0.02)
+
+
+def relerr(a, b):
+    scale = max(1e-30, float(np.max(np.abs(b))))
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) / scale
+
+
+# ------------------------------------------------------------------ single operators
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", CASES)
+def test_update_rating_bit_exact_golden(mfx, name, variant):
+    g, d = load_golden(name)
+    u1, v1 = g["step_u1"].copy(), g["step_v1"].copy()
+    csc, csr = d.csc_val.copy(), d.csr_val.copy()
+    mfx.update_rating(d.csc_col_ptr, d.csc_row_idx, csc, u1, v1, False, variant)
+    mfx.update_rating(d.csr_row_ptr, d.csr_col_idx, csr, v1, u1, False, variant)
+    assert np.array_equal(bits(csc), bits(g["step_csc_sub"]))
+    assert np.array_equal(bits(csr), bits(g["step_csr_sub"]))
+    k = int(g["k"][0]); t1 = 1 % k
+    W0, H0 = g["ccd_T1__W0"], g["ccd_T1__H0"]
+    mfx.update_rating(d.csc_col_ptr, d.csc_row_idx, csc, W0[t1].copy(), H0[t1].copy(), True, variant)
+    mfx.update_rating(d.csr_row_ptr, d.csr_col_idx, csr, H0[t1].copy(), W0[t1].copy(), True, variant)
+    assert np.array_equal(bits(csc), bits(g["step_csc_add"]))
+    assert np.array_equal(bits(csr), bits(g["step_csr_add"]))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("name", CASES)
+def test_rank_one_sweep_golden(mfx, name, variant):
+    g, d = load_golden(name)
+    lam = float(g["lam"][0])
+    v1 = mfx.rank_one_sweep(d.csc_col_ptr, d.csc_row_idx, d.csc_val, g["ccd_T1__W0"][0].copy(), lam, variant)
+    assert relerr(v1, g["step_v1"]) < 2e-5
+    empty = np.diff(d.csc_col_ptr.astype(np.int64)) == 0
+    assert np.all(v1[empty] == 0)  # empty column -> exactly 0 (src/CCD.cpp:8)
+    u1 = mfx.rank_one_sweep(d.csr_row_ptr, d.csr_col_idx, d.csr_val, g["step_v1"].copy(), lam, variant)
+    assert relerr(u1, g["step_u1"]) < 2e-5
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_single_ops_medium(mfx, orc, medium, variant):
+    d = medium
+    rng = np.random.default_rng(3)
+    u = rng.uniform(0.001, 0.101, d.rows).astype(np.float32)
+    v_ref = orc.rank_one_sweep(d.csc_col_ptr, d.csc_row_idx, d.csc_val, u, 0.05, 4)
+    v = mfx.rank_one_sweep(d.csc_col_ptr, d.csc_row_idx, d.csc_val, u, 0.05, variant)
+    assert relerr(v, v_ref) < 2e-5
+    u_ref = orc.rank_one_sweep(d.csr_row_ptr, d.csr_col_idx, d.csr_val, v_ref, 0.05, 4)
+    u2 = mfx.rank_one_sweep(d.csr_row_ptr, d.csr_col_idx, d.csr_val, v_ref, 0.05, variant)
+    assert relerr(u2, u_ref) < 2e-5
+    a, b = d.csr_val.copy(), d.csr_val.copy()
+    orc.update_rating(d.csr_row_ptr, d.csr_col_idx, a, v_ref, u_ref, False, 4)
+    mfx.update_rating(d.csr_row_ptr, d.csr_col_idx, b, v_ref, u_ref, False, variant)
+    assert np.array_equal(bits(a), bits(b))
+
+
+def test_flat_kernel_long_and_degenerate_segments(mfx, orc):
+    """One segment far longer than a span (carries across many spans), runs of 1-entry segments
+    (several heads per lane), empty segments, a tail that is not a multiple of 4."""
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([[0, 0, 20011, 0], np.ones(700, np.int64), [3, 2, 1, 0, 5, 4099, 1, 1, 0, 257, 255, 1023],
+                           rng.integers(0, 40, 300), [7]])
+    ptr = np.zeros(lens.size + 1, np.uint32); ptr[1:] = np.cumsum(lens)
+    nnz, nvec = int(ptr[-1]), 5000
+    idx = rng.integers(0, nvec, nnz).astype(np.uint32)
+    val = rng.uniform(1, 5, nnz).astype(np.float32)
+    vec = rng.uniform(-1, 1, nvec).astype(np.float32)
+    ref = orc.rank_one_sweep(ptr, idx, val, vec, 0.1, 2)
+    # (explicit span lengths are exercised through the resident solver: test_ccdpp_ml1m_shape_vs_oracle)
+    out = mfx.rank_one_sweep(ptr, idx, val, vec, 0.1, 1)
+    assert relerr(out, ref) < 2e-5
+    assert np.all(out[lens == 0] == 0)
+    per_seg = rng.uniform(-1, 1, lens.size).astype(np.float32)
+    a, b = val.copy(), val.copy()
+    orc.update_rating(ptr, idx, a, vec, per_seg, True, 2)
+    mfx.update_rating(ptr, idx, b, vec, per_seg, True, 1)
+    assert np.array_equal(bits(a), bits(b))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_test_rmse_matches_calrmse(mfx, orc, name):
+    g, d = load_golden(name)
+    k = int(g["k"][0])
+    W0, H0 = np.ascontiguousarray(g["ccd_T1__W0"]), np.ascontiguousarray(g["ccd_T1__H0"])
+    got = mfx.test_rmse(mfx.test_data_of(d), W0, H0, d.rows, d.cols, k, False)
+    assert abs(got - float(g["step_rmse_init_ccd"][0])) < 1e-12
+    Wa, Ha = np.ascontiguousarray(g["als__W"]), np.ascontiguousarray(g["als__H"])
+    got = mfx.test_rmse(mfx.test_data_of(d), Wa, Ha, d.rows, d.cols, k, True)
+    assert abs(got - orc.calrmse(d, Wa, Ha, k, True)) < 1e-12
+
+
+# ------------------------------------------------------------------ whole solves, golden
+def _params(mfx, k, lam, t, T, schedule, variant, tiles=0):
+    p = mfx.parameter()
+    p.k, p.lambda_, p.maxiter, p.maxinneriter = k, lam, t, T
+    p.schedule, p.kernel_variant, p.tiles_per_span = schedule, variant, tiles
+    return p
+
+
+SCHEDULES = [(1, 1), (0, 0), (0, 1)]  # (schedule, kernel_variant): fused, as-written wave, as-written flat
+
+
+@pytest.mark.parametrize("schedule,variant", SCHEDULES)
+@pytest.mark.parametrize("tag", ["ccd_T1", "ccd_T3"])
+@pytest.mark.parametrize("name", CASES)
+def test_ccdpp_matches_reference_golden(mfx, name, tag, schedule, variant):
+    """kernel_wrapper_ccdpp_NV vs the reference's own ccdr1_OMP output (tests/golden)."""
+    g, d = load_golden(name)
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    t, T = int(g[tag + "__maxiter"][0]), int(g[tag + "__maxinner"][0])
+    W = np.array(g[tag + "__W0"], np.float32, copy=True)
+    H = np.array(g[tag + "__H0"], np.float32, copy=True)  # content must be ignored (H starts at 0)
+    reports = mfx.kernel_wrapper_ccdpp_NV(d, mfx.test_data_of(d), W, H, _params(mfx, k, lam, t, T, schedule, variant))
+    assert mfx.kernel_wrapper_ccdpp_NV.last_status == 0
+    assert relerr(W, g[tag + "__W"]) < 2e-3 and relerr(H, g[tag + "__H"]) < 2e-3
+    rmse = np.array([r.rmse for r in reports])
+    assert np.all(np.abs(rmse - g[tag + "__rmse"]) < 1e-4), (rmse, g[tag + "__rmse"])
+    assert mfx.golden_compare(W, g[tag + "__W"], k, d.rows, quiet=True) == 0  # the reference's own 10 % bar
+    assert abs(mfx.calculate_rmse_directly(W, H, mfx.test_data_of(d), k, False, quiet=True) - float(g[tag + "__final_rmse"][0])) < 1e-4
+
+
+@pytest.mark.parametrize("schedule,variant", SCHEDULES)
+@pytest.mark.parametrize("name", CASES)
+def test_residual_state_matches_reference(mfx, name, schedule, variant):
+    """After the run both residual copies equal the reference's mutated csc/csr value arrays."""
+    g, d = load_golden(name)
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, 3, 1, schedule, variant))
+    s.set_factors(np.ascontiguousarray(g["ccd_T1__W0"]))
+    s.iterate(3)
+    csc, csr = s.get_residual(d.nnz)
+    s.close()
+    assert np.max(np.abs(csc - g["ccd_T1__csc_val_final"])) < 2e-4
+    assert np.max(np.abs(csr - g["ccd_T1__csr_val_final"])) < 2e-4
+
+
+# ------------------------------------------------------------------ whole solves, ML-1M shape
+@pytest.mark.parametrize("schedule,variant,tiles", [(1, 1, 0), (1, 1, 2), (1, 1, 16), (0, 0, 0), (0, 1, 4)])
+def test_ccdpp_ml1m_shape_vs_oracle(mfx, orc, medium, schedule, variant, tiles):
+    d, k, lam, t = medium, 40, 0.05, 3
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, 1, orc.max_threads())
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, 1, schedule, variant, tiles))
+    s.set_factors(W0.copy())
+    reports = s.iterate(t)
+    W, H = s.get_factors()
+    csc, csr = s.get_residual(d.nnz)
+    s.close()
+    rmse = np.array([r.rmse for r in reports])
+    assert np.all(np.abs(rmse - rmse_ref) < 1e-4), (rmse, rmse_ref)
+    assert relerr(W, Wr) < 2e-3 and relerr(H, Hr) < 2e-3
+    assert mfx.golden_compare(H, Hr, k, d.cols, quiet=True) <= 0.001 * k * d.cols
+    assert np.max(np.abs(csc - csc_ref)) < 1e-3 and np.max(np.abs(csr - csr_ref)) < 1e-3
+
+
+def test_ccdpp_runs_are_bitwise_reproducible_and_split_invariant(mfx, medium):
+    """No atomics anywhere: two solves give identical bits; iterate(1)x3 == iterate(3)."""
+    d, k = medium, 16
+    W0 = mfx.initial_col(k, d.rows)
+    outs = []
+    for split in (False, False, True):
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, 0.05, 3, 1, 1, 1))
+        s.set_factors(W0.copy())
+        if split:
+            for _ in range(3):
+                s.iterate(1)
+        else:
+            s.iterate(3)
+        outs.append(s.get_factors() + s.get_residual(d.nnz))
+        s.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(bits(a), bits(b))
+    for a, b in zip(outs[0], outs[2]):
+        assert np.array_equal(bits(a), bits(b))
+
+
+def test_k1_and_rank_wraparound(mfx, orc):
+    """k = 1: the rank being added back is the rank just subtracted (next == t)."""
+    d = mfx.dataset.synth_ratings(500, 300, 20000, seed=21, skew=0.8, test_frac=0.02)
+    W0 = mfx.initial_col(1, d.rows)
+    Wr, Hr, rmse_ref, *_ = orc.ccdr1(d, W0, 1, 0.05, 4, 2, 2)
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, 1, 0.05, 4, 2, 1, 1))
+    s.set_factors(W0.copy())
+    rep = s.iterate(4)
+    W, H = s.get_factors()
+    s.close()
+    assert relerr(W, Wr) < 1e-3 and relerr(H, Hr) < 1e-3
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-4)
+
+
+def test_errors_are_reported_not_fatal(mfx, medium):
+    p = _params(mfx, 4, 0.05, 1, 1, 1, 1)
+    s = mfx.CcdSolver(medium, None, p)
+    with pytest.raises(mfx.MfxError):
+        s.iterate(1)  # factors not set
+    s.close()
+    p.device = 99
+    with pytest.raises(mfx.MfxError, match="device"):
+        mfx.CcdSolver(medium, None, p)
