@@ -46,6 +46,8 @@ def main() -> None:
     ap.add_argument("--schedule", type=int, default=1)
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--tiles", type=int, default=0)
+    ap.add_argument("--panel-rows", type=int, default=0, help="LDS panel size (0 auto, -1 off)")
+    ap.add_argument("--wg-waves", type=int, default=0, help="waves per workgroup of the panel kernel (0 = 8)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
@@ -90,6 +92,7 @@ def main() -> None:
     p = mfx.parameter()
     p.k, p.lambda_, p.maxinneriter, p.device = a.k, a.lam, a.inner, local_rank
     p.schedule, p.kernel_variant, p.tiles_per_span = a.schedule, a.variant, a.tiles
+    p.panel_rows, p.wg_waves = a.panel_rows, a.wg_waves
     solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt if comm else None,
                            global_test_nnz=ntest_global, device_arrays=d)
     W0 = mfx.initial_col(a.k, int(d["rows"]))  # reference init (glibc rand, seed 0), src/tools.cpp:165-173

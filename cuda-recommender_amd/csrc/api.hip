@@ -184,13 +184,22 @@ struct OpCtx {
 };
 }  // namespace
 
+// variant -> layout of the single-operator entry points (see mfx.h)
+static FlatLayoutOptions op_layout(int variant, int64_t nseg, int64_t nnz, int64_t vec_len) {
+    mfx_params p;
+    mfx_params_default(&p);
+    p.panel_rows = variant >= 16 ? variant : variant == 2 ? 0 : -1;
+    return choose_layout(p, (uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, sizeof(float), variant == 0);
+}
+
 int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
                        int64_t vec_len, const float* vec, float lambda, float* out, int variant, int device) {
     MFX_REQUIRE(nseg > 0 && nnz >= 0 && vec_len > 0 && ptr && vec && out, "mfx_rank_one_sweep: bad argument");
     OpCtx cx;
     MFX_TRY(cx.open(device));
     SegStreamStore s;
-    MFX_TRY(s.build((uint32_t) nseg, (uint64_t) nnz, ptr, idx, val, MFX_HOST, 0, cx.st));
+    MFX_TRY(s.build((uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, ptr, idx, val, MFX_HOST,
+                    op_layout(variant, nseg, nnz, vec_len), cx.st));
     DevBuf<float> dvec, dout, gh;
     MFX_TRY(dvec.alloc(vec_len)); MFX_TRY(dvec.upload(vec, vec_len, MFX_HOST, cx.st));
     MFX_TRY(dout.alloc(nseg));
@@ -215,13 +224,20 @@ int mfx_update_rating(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint
     OpCtx cx;
     MFX_TRY(cx.open(device));
     SegStreamStore s;
-    MFX_TRY(s.build((uint32_t) nseg, (uint64_t) nnz, ptr, idx, val, MFX_HOST, 0, cx.st));
+    MFX_TRY(s.build((uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, ptr, idx, val, MFX_HOST,
+                    op_layout(variant, nseg, nnz, vec_len), cx.st));
     DevBuf<float> dg, dp;
     MFX_TRY(dg.alloc(vec_len)); MFX_TRY(dg.upload(gathered, vec_len, MFX_HOST, cx.st));
     MFX_TRY(dp.alloc(nseg)); MFX_TRY(dp.upload(per_seg, nseg, MFX_HOST, cx.st));
     if (variant == 0) MFX_TRY(launch_resid_wave(s.view, dg.get(), dp.get(), add, cx.st));
     else MFX_TRY(launch_flat(FM_RESID, s.view, dg.get(), dp.get(), add, cx.st));
-    if (nnz) MFX_HIP(hipMemcpyAsync(val, s.view.val, sizeof(float) * nnz, hipMemcpyDeviceToHost, cx.st));
+    if (nnz) {
+        DevBuf<float> tmp;
+        MFX_TRY(tmp.alloc(nnz));
+        MFX_TRY(launch_unpermute(s.view, tmp.get(), cx.st));
+        MFX_HIP(hipMemcpyAsync(val, tmp.get(), sizeof(float) * nnz, hipMemcpyDeviceToHost, cx.st));
+        MFX_HIP(hipStreamSynchronize(cx.st));
+    }
     MFX_HIP(hipStreamSynchronize(cx.st));
     return MFX_OK;
 }

@@ -7,21 +7,71 @@
 // (4) no atomics: every output has exactly one writer, so results are bitwise reproducible.
 #include "ccd_kernels.hpp"
 
+#include <type_traits>
+
 #include "flat_layout.hpp"
 
 namespace mfx {
 namespace {
 
 constexpr int kBlock = 256;  // 4 wavefronts
+constexpr uint32_t kPerSegLdsCap = 1024;  // per-segment operands staged in LDS per workgroup
 
 // native vector types: the non-temporal builtins reject HIP's struct-based uint4/float4
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
 
-__device__ __forceinline__ float wave_sum(float x) {
+__device__ __forceinline__ float wave_sum_shfl(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
+}
+
+// Cross-lane moves on the VALU's DPP path (a few cycles) instead of ds_bpermute (an LDS round trip
+// per step): rows are 16 lanes; row_shr:n shifts inside a row, row_bcast15 / row_bcast31 carry
+// lane 15 / lane 31 into the following row(s), wave_shr:1 shifts the whole wavefront by one lane.
+// Lanes without a source read 0.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_mov(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, ROW_MASK, 0xF, true));
+}
+constexpr int kDppRowShr = 0x110, kDppWaveShr1 = 0x138, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+
+// Sum over the 64 lanes, returned wave-uniform (fixed order: reproducible).
+__device__ __forceinline__ float wave_sum(float x) {
+    const uint32_t lane = threadIdx.x & 63;
+    x += dpp_mov<kDppRowShr + 1>(x);
+    x += dpp_mov<kDppRowShr + 2>(x);
+    x += dpp_mov<kDppRowShr + 4>(x);
+    x += dpp_mov<kDppRowShr + 8>(x);               // lane 15 of each row = row total
+    const float r15 = dpp_mov<kDppBcast15, 0xA>(x);  // rows 1, 3 <- lane 15 of rows 0, 2
+    if (lane & 16) x += r15;
+    const float r31 = dpp_mov<kDppBcast31, 0xC>(x);  // rows 2, 3 <- lane 31
+    if (lane & 32) x += r31;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
+// Inclusive segmented scan over lanes: lane l ends with the sum of x over lanes [h(l), l] where
+// h(l) is the nearest lane <= l that starts a run (bit set in `heads`); dist = l - h(l), or >= 64
+// when no such lane exists.  Unsegmented prefix when heads == 0.
+__device__ __forceinline__ void seg_scan2(float& xg, float& xh, uint32_t lane, uint32_t dist) {
+    const uint32_t in_row = lane & 15;
+#define MFX_SCAN_STEP(D)                                                            \
+    {                                                                               \
+        const float yg = dpp_mov<kDppRowShr + D>(xg), yh = dpp_mov<kDppRowShr + D>(xh); \
+        if (in_row >= D && dist >= D) { xg += yg; xh += yh; }                     \
+    }
+    MFX_SCAN_STEP(1) MFX_SCAN_STEP(2) MFX_SCAN_STEP(4) MFX_SCAN_STEP(8)
+#undef MFX_SCAN_STEP
+    {   // rows 1, 3 take lane 15 of the previous row if no run starts in [row start, l]
+        const float yg = dpp_mov<kDppBcast15, 0xA>(xg), yh = dpp_mov<kDppBcast15, 0xA>(xh);
+        if ((lane & 16) && dist > in_row) { xg += yg; xh += yh; }
+    }
+    {   // rows 2, 3 take lane 31 if no run starts in [32, l]
+        const float yg = dpp_mov<kDppBcast31, 0xC>(xg), yh = dpp_mov<kDppBcast31, 0xC>(xh);
+        if ((lane & 32) && dist > lane - 32) { xg += yg; xh += yh; }
+    }
 }
 
 // Unfused multiply-then-add/sub, like the reference CPU build (no FMA contraction), so that the
@@ -78,17 +128,27 @@ __global__ __launch_bounds__(kBlock) void k_resid_wave(uint32_t nseg, const uint
 
 // ---------------------------------------------------------------------------------------------
 // Variant 1: flat-stream kernel.  One wavefront owns one span of tiles_per_span * 256 consecutive
-// non-zeros; lane l of a tile owns elements 4l..4l+3 (one 16-byte load each of idx and val).
+// stored non-zeros; lane l of a tile owns elements 4l..4l+3 (one 16-byte load each of idx and val).
+//
+// LDS = true (panel layout): a workgroup of BLOCK/64 spans works inside ONE panel.  It first copies
+// that panel's slice of the operand pack into LDS (coalesced, served by L2), then every per-nonzero
+// gather is a ds_read instead of a global load.  Measured on MI355X (profiles/r01_ubench_gather.txt):
+// the same pass runs at 1.8-2.3 TB/s with the gather going to L2 (one 64/128-byte L2 request per
+// 8 useful bytes: request-rate bound) and at 5.5-5.9 TB/s -- the pure streaming rate -- from LDS.
 // ---------------------------------------------------------------------------------------------
 struct FlatArgs {
-    const uint32_t* idx;
+    const void* idx;  // uint32 (plain layout) or uint16 panel-local (LDS panels)
     float* val;
     const uint64_t* flags;
     const uint32_t* seg_of_rank;
     const uint32_t* span_rank_base;
+    const uint32_t* wg_panel;
     uint32_t nspans;
     uint32_t tiles_per_span;
-    uint64_t nnz;
+    uint32_t panel_rows;
+    uint32_t gather_len;
+    uint32_t nne;
+    uint64_t nnz;  // plain layout: elements at or beyond nnz are padding
     const void* gather;
     const void* perseg;
     float* gpart;
@@ -96,6 +156,7 @@ struct FlatArgs {
     float* carry_g;
     float* carry_h;
     int add;
+    int dbg;
 };
 
 template <int MODE> struct ModeTraits;
@@ -103,6 +164,10 @@ template <> struct ModeTraits<FM_SWEEP> { using G = float;  using P = float;  st
 template <> struct ModeTraits<FM_RESID> { using G = float;  using P = float;  static constexpr bool kPerSeg = true,  kWrite = true,  kDot = false; };
 template <> struct ModeTraits<FM_FCSC>  { using G = float2; using P = float2; static constexpr bool kPerSeg = true,  kWrite = true,  kDot = true; };
 template <> struct ModeTraits<FM_FCSR>  { using G = float4; using P = float2; static constexpr bool kPerSeg = true,  kWrite = true,  kDot = true; };
+
+__device__ __forceinline__ float zero_of(float) { return 0.f; }
+__device__ __forceinline__ float2 zero_of(float2) { return make_float2(0.f, 0.f); }
+__device__ __forceinline__ float4 zero_of(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // One element: new residual value and its (g, h) contribution.
 template <int MODE>
@@ -129,61 +194,101 @@ __device__ __forceinline__ void element_op(float v, const typename ModeTraits<MO
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_flat(FlatArgs a) {
+template <int MODE, bool LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     using TR = ModeTraits<MODE>;
     using G = typename TR::G;
     using P = typename TR::P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    G* __restrict__ slice = reinterpret_cast<G*>(lds_raw);
     const uint32_t lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs so that flag words / span metadata become scalar loads
-    const uint32_t span = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
-    if (span >= a.nspans) return;
+    const uint32_t span = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const G* __restrict__ gather = static_cast<const G*>(a.gather);
     const P* __restrict__ perseg = static_cast<const P*>(a.perseg);
+    if constexpr (LDS) {
+        // stage this workgroup's panel slice; slot panel_rows is the zero entry padding points at
+        const uint32_t panel = a.wg_panel[blockIdx.x];
+        const uint32_t gbase = panel * a.panel_rows;
+        const uint32_t cnt = a.gather_len - gbase < a.panel_rows ? a.gather_len - gbase : a.panel_rows;
+        for (uint32_t i = threadIdx.x; i < cnt; i += BLOCK) slice[i] = gather[gbase + i];
+        if (threadIdx.x == 0) slice[a.panel_rows] = zero_of(G{});
+    }
+    // The workgroup touches a contiguous window of ranks; stage their per-segment operands next to
+    // the slice so that segmented tiles read LDS instead of chasing seg_of_rank -> perseg through L2.
+    P* __restrict__ ps_lds = reinterpret_cast<P*>(lds_raw + (((size_t) a.panel_rows + 1) * sizeof(G) + 15) / 16 * 16);
+    int32_t win_base = 0;
+    if constexpr (LDS && TR::kPerSeg) {
+        const uint32_t first = blockIdx.x * (BLOCK / 64), next = first + BLOCK / 64;
+        const int32_t rb0 = (int32_t) a.span_rank_base[first];
+        win_base = rb0 > 0 ? rb0 - 1 : 0;
+        const uint32_t win_end = next < a.nspans ? a.span_rank_base[next] : a.nne;
+        uint32_t cnt = win_end - (uint32_t) win_base;
+        if (cnt > kPerSegLdsCap) cnt = kPerSegLdsCap;
+        for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) ps_lds[j] = perseg[a.seg_of_rank[win_base + j]];
+    }
+    if constexpr (LDS) __syncthreads();
+    if (span >= a.nspans) return;
+    auto fetch_ps = [&](int32_t r) -> P {
+        if constexpr (LDS) {
+            const uint32_t rl = (uint32_t) (r - win_base);
+            if (rl < kPerSegLdsCap) return ps_lds[rl];
+        }
+        return perseg[a.seg_of_rank[r]];
+    };
     const uint64_t start = (uint64_t) span * a.tiles_per_span * kTileElems;
     const int32_t rank_base = (int32_t) a.span_rank_base[span];
     int32_t cur = rank_base - 1;  // rank of the segment that is open at the current position
     P pcur{};
     if constexpr (TR::kPerSeg) {
-        if (cur >= 0) pcur = perseg[a.seg_of_rank[cur]];
+        if (cur >= 0) pcur = fetch_ps(cur);
     }
     float og = 0.f, oh = 0.f;  // per-lane sums of the open segment since its last head
 
-    const u32x4* __restrict__ idx4 = reinterpret_cast<const u32x4*>(a.idx + start) + lane;
+    // panel-local indices are 16-bit: 2 B/nnz instead of 4 (10 B/nnz per fused pass instead of 12)
+    using IdxVec = typename std::conditional<LDS, u16x4, u32x4>::type;
+    using IdxElem = typename std::conditional<LDS, uint16_t, uint32_t>::type;
+    const IdxVec* __restrict__ idx4 = reinterpret_cast<const IdxVec*>(static_cast<const IdxElem*>(a.idx) + start) + lane;
     f32x4* __restrict__ val4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
     uint32_t ntiles = a.tiles_per_span;
-    {   // tiles that start at or beyond nnz hold only padding
+    if constexpr (!LDS) {  // plain layout: tiles that start at or beyond nnz hold only padding
         const uint64_t left = a.nnz > start ? a.nnz - start : 0;
         const uint32_t live = (uint32_t) ((left + kTileElems - 1) / kTileElems);
         if (live < ntiles) ntiles = live;
     }
-    u32x4 id_n = {0, 0, 0, 0};
+    IdxVec id_n = {0, 0, 0, 0};
     f32x4 v_n = {0.f, 0.f, 0.f, 0.f};
+    const uint64_t* __restrict__ fw = a.flags + (start >> 6);  // 4 words per tile, wave-uniform (scalar loads)
+    uint64_t f0_n = 0, f1_n = 0, f2_n = 0, f3_n = 0;
     if (ntiles) {
         id_n = __builtin_nontemporal_load(idx4);
         v_n = __builtin_nontemporal_load(val4);
+        f0_n = fw[0]; f1_n = fw[1]; f2_n = fw[2]; f3_n = fw[3];
     }
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
-        const u32x4 id = id_n;
+        const IdxVec id = id_n;
         const f32x4 v = v_n;
-        if (tile + 1 < ntiles) {  // prefetch the next tile's streams (one tile ahead)
+        const uint64_t w0 = f0_n, w1 = f1_n, w2 = f2_n, w3 = f3_n;
+        if (tile + 1 < ntiles) {  // prefetch the next tile's streams and head flags (one tile ahead)
             id_n = __builtin_nontemporal_load(idx4 + (tile + 1) * 64);
             v_n = __builtin_nontemporal_load(val4 + (tile + 1) * 64);
+            const uint64_t* fn = fw + (tile + 1) * 4;
+            f0_n = fn[0]; f1_n = fn[1]; f2_n = fn[2]; f3_n = fn[3];
         }
         const uint64_t base = start + (uint64_t) tile * kTileElems;
-        const uint64_t* fw = a.flags + (base >> 6);
-        const uint64_t w0 = fw[0], w1 = fw[1], w2 = fw[2], w3 = fw[3];
-        const bool partial = base + kTileElems > a.nnz;  // wave-uniform: tile straddles the end
+        // plain layout only: the tile that straddles nnz needs its padding masked; with LDS panels
+        // padding gathers the zero slot and contributes exact zeros
+        const bool partial = !LDS && base + kTileElems > a.nnz;
         const uint64_t e0 = base + (uint64_t) lane * 4;
 
-        const uint32_t ids[4] = {id.x, id.y, id.z, id.w};
+        const uint32_t ids[4] = {(uint32_t) id.x, (uint32_t) id.y, (uint32_t) id.z, (uint32_t) id.w};
         const float vs[4] = {v.x, v.y, v.z, v.w};
         G ga[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ga[e] = gather[ids[e]];
+        for (int e = 0; e < 4; ++e) ga[e] = LDS ? slice[ids[e]] : gather[ids[e]];
         float vo[4], gc[4], hc[4];
 
-        if ((w0 | w1 | w2 | w3) == 0) {
+        if ((w0 | w1 | w2 | w3) == 0 || (a.dbg & 1)) {
             // ---- no segment starts in this tile: everything belongs to the open segment ----
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -207,12 +312,12 @@ __global__ __launch_bounds__(kBlock) void k_flat(FlatArgs a) {
                 P ps{};
                 if constexpr (TR::kPerSeg) {
                     const int32_t r = cur + (int32_t) before + (int32_t) __popc(nib & ((2u << e) - 1u));
-                    ps = perseg[a.seg_of_rank[r]];
+                    ps = (a.dbg & 2) ? pcur : fetch_ps(r);
                 }
                 element_op<MODE>(vs[e], ga[e], ps, a.add, vo[e], gc[e], hc[e]);
                 if (partial && e0 + e >= a.nnz) { gc[e] = 0.f; hc[e] = 0.f; }
             }
-            if constexpr (TR::kDot) {
+            if (TR::kDot && !(a.dbg & 4)) {
                 // carry-in: the open segment's sum so far, as a wave-uniform value
                 const float cin_g = wave_sum(og), cin_h = wave_sum(oh);
                 // lane-serial pass: fg/fh = run before the lane's first head, ag/ah = run after its
@@ -238,17 +343,11 @@ __global__ __launch_bounds__(kBlock) void k_flat(FlatArgs a) {
                 if (!seen) { fg = ag; fh = ah; }
                 // segmented inclusive scan over lanes of the right-propagating value
                 const uint64_t M = __ballot(seen);
+                const uint64_t upto = M & ((uint64_t(2) << lane) - 1);  // head lanes <= this lane
+                const uint32_t dist = upto ? lane - (63u - (uint32_t) __clzll((long long) upto)) : 64u;
                 float xg = ag, xh = ah;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const float yg = __shfl_up(xg, d, 64), yh = __shfl_up(xh, d, 64);
-                    // add lanes [l-2d+1, l-d] only if no head lane lies in (l-d, l]
-                    const uint32_t lo_bit = lane >= (uint32_t) d ? lane - d + 1 : 0u;
-                    const bool ok = lane >= (uint32_t) d && ((M >> lo_bit) & ((uint64_t(1) << d) - 1)) == 0;
-                    if (ok) { xg += yg; xh += yh; }
-                }
-                float eg = __shfl_up(xg, 1, 64), eh = __shfl_up(xh, 1, 64);
-                if (lane == 0) { eg = 0.f; eh = 0.f; }
+                seg_scan2(xg, xh, lane, dist);
+                float eg = dpp_mov<kDppWaveShr1>(xg), eh = dpp_mov<kDppWaveShr1>(xh);  // exclusive: lane l-1
                 if ((M & ((uint64_t(1) << lane) - 1)) == 0) { eg += cin_g; eh += cin_h; }
                 if (seen) {  // this lane's first head closes the segment of rank cur+before
                     const int32_t rc = cur + (int32_t) before;
@@ -262,12 +361,13 @@ __global__ __launch_bounds__(kBlock) void k_flat(FlatArgs a) {
                     }
                 }
                 // new open segment: everything after the tile's last head
-                const float ng = __shfl(xg, 63, 64), nh = __shfl(xh, 63, 64);
+                const float ng = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xg), 63));
+                const float nh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xh), 63));
                 og = lane == 0 ? ng : 0.f;
                 oh = lane == 0 ? nh : 0.f;
             }
             cur += (int32_t) ctot;
-            if constexpr (TR::kPerSeg) pcur = perseg[a.seg_of_rank[cur]];
+            if constexpr (TR::kPerSeg) pcur = fetch_ps(cur);
         }
         if constexpr (TR::kWrite) {
             if (!partial) {
@@ -294,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void k_flat(FlatArgs a) {
     }
 }
 
-// Adds, in span order, the carries that belong to segment [lo, hi).
+// Adds, in span order, the carries that belong to the stored range [lo, hi).
 __device__ __forceinline__ void add_carries(uint32_t lo, uint32_t hi, uint32_t span_len,
                                             const float* __restrict__ cg, const float* __restrict__ ch,
                                             float& g, float& h) {
@@ -309,32 +409,65 @@ __device__ __forceinline__ void add_carries(uint32_t lo, uint32_t hi, uint32_t s
     for (; s <= s_end; ++s) { g += cg[s]; h += ch[s]; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_combine_dense(uint32_t nseg, uint32_t span_len,
-                                                          const uint32_t* __restrict__ ptr,
-                                                          const int32_t* __restrict__ rank_of_seg,
-                                                          const float* __restrict__ gpart,
-                                                          const float* __restrict__ hpart,
-                                                          const float* __restrict__ cg,
-                                                          const float* __restrict__ ch,
-                                                          float* __restrict__ gh) {
-    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= nseg) return;
-    float g = 0.f, h = 0.f;
-    const int32_t r = rank_of_seg[c];
-    if (r >= 0) {
-        g = gpart[r];
-        h = hpart[r];
-        add_carries(ptr[c], ptr[c + 1], span_len, cg, ch, g, h);
+struct GatherPartsArgs {
+    uint32_t nseg, npanels, span_len;
+    const uint32_t* ptr_v;
+    const int32_t* rank_of_seg;
+    const float *gpart, *hpart, *cg, *ch;
+};
+
+// (g, h) of real segment c over panels p0, p0 + stride, ...: each virtual segment = part + carries.
+__device__ __forceinline__ void segment_sums(const GatherPartsArgs& a, uint32_t c, uint32_t p0, uint32_t stride,
+                                             float& g, float& h) {
+    g = 0.f;
+    h = 0.f;
+    for (uint32_t p = p0; p < a.npanels; p += stride) {
+        const size_t v = (size_t) p * a.nseg + c;
+        const int32_t r = a.rank_of_seg[v];
+        if (r >= 0) {
+            float pg = a.gpart[r], ph = a.hpart[r];
+            add_carries(a.ptr_v[v], a.ptr_v[v + 1], a.span_len, a.cg, a.ch, pg, ph);
+            g += pg;
+            h += ph;
+        }
     }
+}
+
+// PL "panel lanes" cooperate on one segment (each walks every PL-th panel: the per-panel lookups
+// are a chain of three dependent loads, so 59 panels walked by one thread cost ~40 us); their
+// partial sums are added in lane order through LDS -- a fixed order, so still reproducible.
+template <int PL>
+__device__ __forceinline__ bool block_segment_sums(const GatherPartsArgs& a, uint32_t& c, float& g, float& h) {
+    constexpr int SEGS = kBlock / PL;
+    __shared__ float sg[kBlock], sh[kBlock];
+    const uint32_t sl = threadIdx.x % SEGS, pl = threadIdx.x / SEGS;
+    c = blockIdx.x * SEGS + sl;
+    g = 0.f;
+    h = 0.f;
+    if (c < a.nseg) segment_sums(a, c, pl, PL, g, h);
+    if constexpr (PL > 1) {
+        sg[threadIdx.x] = g;
+        sh[threadIdx.x] = h;
+        __syncthreads();
+        if (pl == 0) {
+            for (int q = 1; q < PL; ++q) { g += sg[q * SEGS + sl]; h += sh[q * SEGS + sl]; }
+        }
+    }
+    return pl == 0 && c < a.nseg;
+}
+
+template <int PL>
+__global__ __launch_bounds__(kBlock) void k_combine_dense(GatherPartsArgs a, float* __restrict__ gh) {
+    uint32_t c;
+    float g, h;
+    if (!block_segment_sums<PL>(a, c, g, h)) return;
     gh[c] = g;
-    gh[nseg + c] = h;
+    gh[a.nseg + c] = h;
 }
 
 struct FinKernelArgs {
-    uint32_t nseg, span_len;
-    const uint32_t* ptr;
-    const int32_t* rank_of_seg;
-    const float *gpart, *hpart, *cg, *ch;
+    GatherPartsArgs parts;
+    const uint32_t* seg_cnt;
     const float* gh_dense;
     const uint32_t* cnt_override;
     float lambda;
@@ -344,23 +477,19 @@ struct FinKernelArgs {
     float4* pack4;
 };
 
+template <int PL>
 __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
-    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= a.nseg) return;
-    const uint32_t lo = a.ptr[c], hi = a.ptr[c + 1];
-    float g = 0.f, h = 0.f;
-    if (a.gh_dense) {
+    uint32_t c;
+    float g, h;
+    if (a.gh_dense) {  // PL == 1 by construction
+        c = blockIdx.x * kBlock + threadIdx.x;
+        if (c >= a.parts.nseg) return;
         g = a.gh_dense[c];
-        h = a.gh_dense[a.nseg + c];
-    } else {
-        const int32_t r = a.rank_of_seg[c];
-        if (r >= 0) {
-            g = a.gpart[r];
-            h = a.hpart[r];
-            add_carries(lo, hi, a.span_len, a.cg, a.ch, g, h);
-        }
+        h = a.gh_dense[a.parts.nseg + c];
+    } else if (!block_segment_sums<PL>(a.parts, c, g, h)) {
+        return;
     }
-    const uint32_t cnt = a.cnt_override ? a.cnt_override[c] : hi - lo;
+    const uint32_t cnt = a.cnt_override ? a.cnt_override[c] : a.seg_cnt[c];
     // reference: g / (lambda * |Omega| + sum u^2), 0 for an empty segment (src/CCD.cpp:6-16,112)
     const float x = cnt ? g / add_rn(mul_rn(a.lambda, (float) cnt), h) : 0.f;
     a.out_vec[c] = x;
@@ -369,6 +498,14 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
         if (a.pack4) a.pack4[c] = make_float4(old.x, old.y, x, 0.f);
         a.pack2[c] = make_float2(x, a.next_vec[c]);
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_unpermute(uint64_t n, const uint32_t* __restrict__ perm,
+                                                      const float* __restrict__ val, float* __restrict__ out) {
+    const uint64_t e = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t q = perm[e];
+    if (q != ~0u) out[q] = val[e];
 }
 
 __global__ __launch_bounds__(kBlock) void k_pack2(uint32_t n, const float* __restrict__ x,
@@ -431,27 +568,60 @@ uint32_t seg_grid(uint32_t nseg) {
 
 #define MFX_LAUNCH_CHECK() MFX_HIP(hipGetLastError())
 
-int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, int add,
-                hipStream_t st) {
-    FlatArgs a;
-    a.idx = s.idx; a.val = s.val; a.flags = s.flags; a.seg_of_rank = s.seg_of_rank;
-    a.span_rank_base = s.span_rank_base; a.nspans = s.nspans; a.tiles_per_span = s.tiles_per_span;
-    a.nnz = s.nnz; a.gather = gather; a.perseg = perseg; a.gpart = s.gpart; a.hpart = s.hpart;
-    a.carry_g = s.carry_g; a.carry_h = s.carry_h; a.add = add;
-    const dim3 grid((s.nspans + (kBlock / 64) - 1) / (kBlock / 64)), block(kBlock);
-    switch (mode) {
-        case FM_SWEEP: hipLaunchKernelGGL(k_flat<FM_SWEEP>, grid, block, 0, st, a); break;
-        case FM_RESID: hipLaunchKernelGGL(k_flat<FM_RESID>, grid, block, 0, st, a); break;
-        case FM_FCSC: hipLaunchKernelGGL(k_flat<FM_FCSC>, grid, block, 0, st, a); break;
-        case FM_FCSR: hipLaunchKernelGGL(k_flat<FM_FCSR>, grid, block, 0, st, a); break;
-        default: return fail(MFX_ERR_INVALID, "launch_flat: bad mode %d", (int) mode);
+template <int MODE, bool LDS, int BLOCK>
+int launch_flat_t(const FlatArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
+    if (lds_bytes > 48 * 1024) {
+        static size_t attr_bytes = 0;  // per instantiation
+        if (lds_bytes > attr_bytes) {
+            MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat<MODE, LDS, BLOCK>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+            attr_bytes = lds_bytes;
+        }
     }
+    hipLaunchKernelGGL((k_flat<MODE, LDS, BLOCK>), dim3(grid), dim3(BLOCK), lds_bytes, st, a);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }
 
+template <int MODE>
+int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
+    using G = typename ModeTraits<MODE>::G;
+    if (s.panel_rows == 0)
+        return launch_flat_t<MODE, false, kBlock>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), 0, st);
+    size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(G) + 15) / 16 * 16;
+    if (ModeTraits<MODE>::kPerSeg) lds_bytes += (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
+    const uint32_t grid = s.nspans / s.spans_per_wg;
+    switch (s.spans_per_wg) {
+        case 4: return launch_flat_t<MODE, true, 256>(a, grid, lds_bytes, st);
+        case 8: return launch_flat_t<MODE, true, 512>(a, grid, lds_bytes, st);
+        case 16: return launch_flat_t<MODE, true, 1024>(a, grid, lds_bytes, st);
+        default: return fail(MFX_ERR_INVALID, "panel layout: spans_per_wg must be 4, 8 or 16 (got %u)", s.spans_per_wg);
+    }
+}
+
+int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, int add,
+                hipStream_t st) {
+    FlatArgs a;
+    a.idx = s.panel_rows ? static_cast<const void*>(s.idx16) : static_cast<const void*>(s.idx);
+    a.val = s.val; a.flags = s.flags; a.seg_of_rank = s.seg_of_rank;
+    a.span_rank_base = s.span_rank_base; a.wg_panel = s.wg_panel; a.nspans = s.nspans;
+    a.tiles_per_span = s.tiles_per_span; a.panel_rows = s.panel_rows; a.gather_len = s.gather_len; a.nne = s.nne;
+    a.nnz = s.nnz; a.gather = gather; a.perseg = perseg; a.gpart = s.gpart; a.hpart = s.hpart;
+    a.carry_g = s.carry_g; a.carry_h = s.carry_h; a.add = add;
+    static const int dbg = getenv("MFX_DBG") ? atoi(getenv("MFX_DBG")) : 0;
+    a.dbg = dbg;
+    switch (mode) {
+        case FM_SWEEP: return launch_flat_mode<FM_SWEEP>(s, a, st);
+        case FM_RESID: return launch_flat_mode<FM_RESID>(s, a, st);
+        case FM_FCSC: return launch_flat_mode<FM_FCSC>(s, a, st);
+        case FM_FCSR: return launch_flat_mode<FM_FCSR>(s, a, st);
+        default: return fail(MFX_ERR_INVALID, "launch_flat: bad mode %d", (int) mode);
+    }
+}
+
 int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, float* h_dense, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
+    MFX_REQUIRE(s.panel_rows == 0, "wave-per-segment kernels need the plain layout");
     hipLaunchKernelGGL(k_sweep_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
                        vec, g_dense, h_dense);
     MFX_LAUNCH_CHECK();
@@ -460,17 +630,30 @@ int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, f
 
 int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float* per_seg, int add, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
+    MFX_REQUIRE(s.panel_rows == 0, "wave-per-segment kernels need the plain layout");
     hipLaunchKernelGGL(k_resid_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
                        gathered, per_seg, add);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }
 
+static GatherPartsArgs parts_of(const SegStreamDev& s) {
+    GatherPartsArgs g;
+    g.nseg = s.nseg; g.npanels = s.npanels; g.span_len = s.tiles_per_span * kTileElems; g.ptr_v = s.ptr_v;
+    g.rank_of_seg = s.rank_of_seg; g.gpart = s.gpart; g.hpart = s.hpart; g.cg = s.carry_g; g.ch = s.carry_h;
+    return g;
+}
+
+static int panel_lanes(const SegStreamDev& s) { return s.npanels >= 8 ? 16 : s.npanels >= 2 ? 4 : 1; }
+
 int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
-    hipLaunchKernelGGL(k_combine_dense, dim3((s.nseg + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.nseg,
-                       s.tiles_per_span * kTileElems, s.ptr, s.rank_of_seg, s.gpart, s.hpart, s.carry_g,
-                       s.carry_h, gh);
+    const GatherPartsArgs a = parts_of(s);
+    const int pl = panel_lanes(s);
+    const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
+    if (pl == 16) hipLaunchKernelGGL(k_combine_dense<16>, grid, block, 0, st, a, gh);
+    else if (pl == 4) hipLaunchKernelGGL(k_combine_dense<4>, grid, block, 0, st, a, gh);
+    else hipLaunchKernelGGL(k_combine_dense<1>, grid, block, 0, st, a, gh);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }
@@ -478,11 +661,21 @@ int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st) {
 int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
     FinKernelArgs a;
-    a.nseg = s.nseg; a.span_len = s.tiles_per_span * kTileElems; a.ptr = s.ptr; a.rank_of_seg = s.rank_of_seg;
-    a.gpart = s.gpart; a.hpart = s.hpart; a.cg = s.carry_g; a.ch = s.carry_h; a.gh_dense = f.gh_dense;
-    a.cnt_override = f.cnt_override; a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2;
-    a.next_vec = f.next_vec; a.pack4 = f.pack4;
-    hipLaunchKernelGGL(k_finalize, dim3((s.nseg + kBlock - 1) / kBlock), dim3(kBlock), 0, st, a);
+    a.parts = parts_of(s); a.seg_cnt = s.seg_cnt; a.gh_dense = f.gh_dense; a.cnt_override = f.cnt_override;
+    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
+    const int pl = f.gh_dense ? 1 : panel_lanes(s);
+    const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
+    if (pl == 16) hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, st, a);
+    else if (pl == 4) hipLaunchKernelGGL(k_finalize<4>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(k_finalize<1>, grid, block, 0, st, a);
+    MFX_LAUNCH_CHECK();
+    return MFX_OK;
+}
+
+int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st) {
+    if (s.padded_nnz == 0) return MFX_OK;
+    hipLaunchKernelGGL(k_unpermute, dim3((uint32_t) ((s.padded_nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       s.padded_nnz, s.perm, s.val, out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }

@@ -15,18 +15,28 @@ namespace mfx {
 // Device view of one orientation of the residual matrix (CSC: segments = columns, gathered
 // index = row; CSR: the transpose) together with its flat-stream metadata.
 struct SegStreamDev {
-    uint32_t nseg = 0;
-    uint32_t nne = 0;
-    uint64_t nnz = 0;
+    uint32_t nseg = 0;         // real segments
+    uint32_t nne = 0;          // non-empty virtual segments
+    uint64_t nnz = 0;          // real non-zeros
+    uint64_t padded_nnz = 0;   // stored elements
     uint32_t nspans = 0;
     uint32_t tiles_per_span = 0;
-    const uint32_t* ptr = nullptr;             // [nseg+1]
-    const uint32_t* idx = nullptr;             // [padded nnz]
-    float* val = nullptr;                      // [padded nnz]  residual copy, updated in place
+    uint32_t npanels = 1;
+    uint32_t panel_rows = 0;   // 0: plain layout, gather from global memory
+    uint32_t spans_per_wg = 1;
+    uint32_t gather_len = 0;
+    const uint32_t* ptr = nullptr;             // [nseg+1] input-order pointers (plain layout only)
+    const uint32_t* ptr_v = nullptr;           // [npanels*nseg+1] virtual-segment pointers (stored coords)
+    const uint32_t* seg_cnt = nullptr;         // [nseg]
+    const uint32_t* idx = nullptr;             // [padded nnz] gathered index (plain layout)
+    const uint16_t* idx16 = nullptr;           // [padded nnz] panel-local gathered index (LDS panels)
+    float* val = nullptr;                      // [padded nnz] residual copy, updated in place
     const uint64_t* flags = nullptr;           // [padded nnz / 64]
-    const int32_t* rank_of_seg = nullptr;      // [nseg]
-    const uint32_t* seg_of_rank = nullptr;     // [nne]
+    const int32_t* rank_of_seg = nullptr;      // [npanels*nseg]
+    const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id
     const uint32_t* span_rank_base = nullptr;  // [nspans]
+    const uint32_t* wg_panel = nullptr;        // [nspans/spans_per_wg]
+    const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding
     // reduction scratch written by the flat kernels
     float* gpart = nullptr;    // [nne]
     float* hpart = nullptr;    // [nne]
@@ -47,7 +57,7 @@ enum FlatMode : int {
 int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg,
                 int add, hipStream_t st);
 
-// Wave-per-segment kernels.
+// Wave-per-segment kernels (plain layout only: they walk the input-order arrays).
 int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, float* h_dense,
                       hipStream_t st);
 int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float* per_seg, int add,
@@ -61,7 +71,7 @@ int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st);
 // dense, already all-reduced buffer gh_dense[2*nseg].
 struct FinalizeArgs {
     const float* gh_dense = nullptr;    // [2*nseg] or nullptr
-    const uint32_t* cnt_override = nullptr;  // global |Omega_c| (multi-GPU) or nullptr = ptr diff
+    const uint32_t* cnt_override = nullptr;  // global |Omega_c| (multi-GPU) or nullptr = local count
     float lambda = 0.f;
     float* out_vec = nullptr;           // W[t] / H[t] slice, [nseg]
     float2* pack2 = nullptr;            // in: (prev_new, cur_old); out: (cur_new, next_old)
@@ -69,6 +79,9 @@ struct FinalizeArgs {
     float4* pack4 = nullptr;            // out: (prev_new, cur_old, cur_new, 0), may be nullptr
 };
 int launch_finalize(const SegStreamDev& s, const FinalizeArgs& a, hipStream_t st);
+
+// out[perm[e]] = val[e] for every stored, non-padding element: residual back in input order.
+int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st);
 
 // pack[i] = (x ? x[i] : 0, y[i])
 int launch_pack2(uint32_t n, const float* x, const float* y, float2* pack, hipStream_t st);

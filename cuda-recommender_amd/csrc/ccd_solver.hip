@@ -15,35 +15,78 @@
 namespace mfx {
 
 // ------------------------------------------------------------------------------------------------
-int SegStreamStore::build(uint32_t nseg, uint64_t nnz, const uint32_t* ptr, const uint32_t* idx,
-                          const float* val, mfx_memspace space, uint32_t tiles_per_span, hipStream_t st) {
-    std::vector<uint32_t> ptr_host_buf;
-    const uint32_t* ptr_host = ptr;
+int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx,
+                          const float* val, mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st) {
+    // The layout is built on the host (one pass over the pattern, a few threads); device-resident
+    // inputs are brought down once for it.  One-time setup, outside every timed region.
+    std::vector<uint32_t> ptr_buf, idx_buf;
+    std::vector<float> val_buf;
+    const uint32_t* ptr_h = ptr;
+    const uint32_t* idx_h = idx;
+    const float* val_h = val;
     if (space == MFX_DEVICE) {
-        ptr_host_buf.resize((size_t) nseg + 1);
-        MFX_HIP(hipMemcpy(ptr_host_buf.data(), ptr, sizeof(uint32_t) * ((size_t) nseg + 1), hipMemcpyDeviceToHost));
-        ptr_host = ptr_host_buf.data();
+        ptr_buf.resize((size_t) nseg + 1);
+        MFX_HIP(hipMemcpy(ptr_buf.data(), ptr, sizeof(uint32_t) * ptr_buf.size(), hipMemcpyDeviceToHost));
+        ptr_h = ptr_buf.data();
+        idx_buf.resize(nnz);
+        if (nnz) MFX_HIP(hipMemcpy(idx_buf.data(), idx, sizeof(uint32_t) * nnz, hipMemcpyDeviceToHost));
+        idx_h = idx_buf.data();
+        if (val) {
+            val_buf.resize(nnz);
+            if (nnz) MFX_HIP(hipMemcpy(val_buf.data(), val, sizeof(float) * nnz, hipMemcpyDeviceToHost));
+            val_h = val_buf.data();
+        }
     }
-    MFX_REQUIRE(ptr_host[0] == 0 && ptr_host[nseg] == nnz, "segment pointer array does not span [0, nnz]");
+    MFX_REQUIRE(ptr_h[0] == 0 && ptr_h[nseg] == nnz, "segment pointer array does not span [0, nnz]");
     for (uint32_t c = 0; c < nseg; ++c)
-        MFX_REQUIRE(ptr_host[c] <= ptr_host[c + 1], "segment pointer array is not monotone at %u", c);
-    build_flat_layout(ptr_host, nseg, nnz, tiles_per_span, &layout_);
-    const FlatLayoutHost& L = layout_;
+        MFX_REQUIRE(ptr_h[c] <= ptr_h[c + 1], "segment pointer array is not monotone at %u", c);
+    for (uint64_t q = 0; q < nnz; ++q)
+        MFX_REQUIRE(idx_h[q] < G, "index %u at position %llu is out of range [0, %u)", idx_h[q], (unsigned long long) q, G);
+    if (opt.panel_rows) {
+        MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16,
+                    "wg_waves must be 4, 8 or 16");
+    }
+    build_flat_layout(ptr_h, idx_h, nseg, nnz, G, opt, &layout_);
+    FlatLayoutHost& L = layout_;
+    MFX_REQUIRE(L.padded_nnz < 0xFFFFFF00ull, "padded non-zero count exceeds the 32-bit position range");
 
+    std::vector<float> val_st(L.padded_nnz, 0.f);
+    if (val_h)
+        for (uint64_t e = 0; e < L.padded_nnz; ++e)
+            if (L.perm[e] != ~0u) val_st[e] = val_h[L.perm[e]];
+
+    const size_t nv = (size_t) L.npanels * nseg;
     MFX_TRY(ptr_.alloc((size_t) nseg + 1));
-    MFX_TRY(ptr_.upload(ptr_host, (size_t) nseg + 1, MFX_HOST, st));
-    MFX_TRY(idx_.alloc_zero(L.padded_nnz, st));
-    MFX_TRY(idx_.upload(idx, nnz, space, st));
-    MFX_TRY(val_.alloc_zero(L.padded_nnz, st));
-    if (val) MFX_TRY(val_.upload(val, nnz, space, st));
+    MFX_TRY(ptr_.upload(ptr_h, (size_t) nseg + 1, MFX_HOST, st));
+    MFX_TRY(ptr_v_.alloc(nv + 1));
+    MFX_TRY(ptr_v_.upload(L.ptr_v.data(), nv + 1, MFX_HOST, st));
+    MFX_TRY(seg_cnt_.alloc(nseg));
+    MFX_TRY(seg_cnt_.upload(L.seg_cnt.data(), nseg, MFX_HOST, st));
+    std::vector<uint16_t> idx16;
+    if (L.panel_rows) {  // panel-local indices (and the zero slot, index panel_rows) fit 16 bits
+        MFX_REQUIRE(L.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
+        idx16.resize(L.padded_nnz);
+        for (uint64_t e = 0; e < L.padded_nnz; ++e) idx16[e] = (uint16_t) L.idx_local[e];
+        MFX_TRY(idx16_.alloc(L.padded_nnz));
+        MFX_TRY(idx16_.upload(idx16.data(), L.padded_nnz, MFX_HOST, st));
+    } else {
+        MFX_TRY(idx_.alloc(L.padded_nnz));
+        MFX_TRY(idx_.upload(L.idx_local.data(), L.padded_nnz, MFX_HOST, st));
+    }
+    MFX_TRY(perm_.alloc(L.padded_nnz));
+    MFX_TRY(perm_.upload(L.perm.data(), L.padded_nnz, MFX_HOST, st));
+    MFX_TRY(val_.alloc(L.padded_nnz));
+    MFX_TRY(val_.upload(val_st.data(), L.padded_nnz, MFX_HOST, st));
     MFX_TRY(flags_.alloc(L.flags.size()));
     MFX_TRY(flags_.upload(L.flags.data(), L.flags.size(), MFX_HOST, st));
-    MFX_TRY(rank_of_seg_.alloc(nseg));
-    MFX_TRY(rank_of_seg_.upload(L.rank_of_seg.data(), nseg, MFX_HOST, st));
+    MFX_TRY(rank_of_seg_.alloc(nv));
+    MFX_TRY(rank_of_seg_.upload(L.rank_of_seg.data(), nv, MFX_HOST, st));
     MFX_TRY(seg_of_rank_.alloc(L.nne ? L.nne : 1));
     MFX_TRY(seg_of_rank_.upload(L.seg_of_rank.data(), L.nne, MFX_HOST, st));
     MFX_TRY(span_rank_base_.alloc(L.nspans));
     MFX_TRY(span_rank_base_.upload(L.span_rank_base.data(), L.nspans, MFX_HOST, st));
+    MFX_TRY(wg_panel_.alloc(L.wg_panel.empty() ? 1 : L.wg_panel.size()));
+    MFX_TRY(wg_panel_.upload(L.wg_panel.data(), L.wg_panel.size(), MFX_HOST, st));
     MFX_TRY(gpart_.alloc_zero(L.nne ? L.nne : 1, st));
     MFX_TRY(hpart_.alloc_zero(L.nne ? L.nne : 1, st));
     MFX_TRY(carry_g_.alloc_zero(L.nspans, st));
@@ -51,15 +94,39 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, const uint32_t* ptr, cons
     // the host vectors behind the async uploads must outlive the copies
     MFX_HIP(hipStreamSynchronize(st));
 
-    view.nseg = nseg; view.nne = L.nne; view.nnz = nnz; view.nspans = L.nspans;
-    view.tiles_per_span = L.tiles_per_span;
-    view.ptr = ptr_.get(); view.idx = idx_.get(); view.val = val_.get(); view.flags = flags_.get();
-    view.rank_of_seg = rank_of_seg_.get(); view.seg_of_rank = seg_of_rank_.get();
-    view.span_rank_base = span_rank_base_.get(); view.gpart = gpart_.get(); view.hpart = hpart_.get();
+    view.nseg = nseg; view.nne = L.nne; view.nnz = nnz; view.padded_nnz = L.padded_nnz; view.nspans = L.nspans;
+    view.tiles_per_span = L.tiles_per_span; view.npanels = L.npanels; view.panel_rows = L.panel_rows;
+    view.spans_per_wg = L.spans_per_wg; view.gather_len = G;
+    view.ptr = ptr_.get(); view.ptr_v = ptr_v_.get(); view.seg_cnt = seg_cnt_.get(); view.idx = idx_.get();
+    view.idx16 = idx16_.get();
+    view.val = val_.get(); view.flags = flags_.get(); view.rank_of_seg = rank_of_seg_.get();
+    view.seg_of_rank = seg_of_rank_.get(); view.span_rank_base = span_rank_base_.get();
+    view.wg_panel = wg_panel_.get(); view.perm = perm_.get(); view.gpart = gpart_.get(); view.hpart = hpart_.get();
     view.carry_g = carry_g_.get(); view.carry_h = carry_h_.get();
-    // the big host-side flag vector is no longer needed
-    layout_.flags.clear(); layout_.flags.shrink_to_fit();
+    // the big host-side vectors are no longer needed
+    for (auto* v : {&L.idx_local, &L.perm}) { v->clear(); v->shrink_to_fit(); }
+    L.flags.clear(); L.flags.shrink_to_fit();
     return MFX_OK;
+}
+
+// LDS panels pay off when the gathered vector is too big for L1 yet cutting it into LDS-sized
+// panels leaves virtual segments long enough to amortise the per-segment bookkeeping.
+FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz, uint32_t G, uint32_t elem_bytes,
+                                bool need_plain) {
+    FlatLayoutOptions o;
+    o.tiles_per_span = p.tiles_per_span > 0 ? (uint32_t) p.tiles_per_span : 0;
+    // 16 waves x 2 workgroups (64 KB of LDS each) = 32 resident waves per CU
+    o.spans_per_wg = p.wg_waves > 0 ? (uint32_t) p.wg_waves : 16;
+    o.panel_rows = 0;
+    if (need_plain || p.panel_rows < 0) return o;
+    // 64 KB of LDS per workgroup: 8 KB for the staged per-segment operands, the rest for the slice
+    uint32_t pr = p.panel_rows > 0 ? (uint32_t) p.panel_rows : (56u * 1024u) / elem_bytes - 1;
+    if (pr >= G) pr = G;  // the whole gathered vector fits: one panel
+    const uint64_t npanels = (G + pr - 1) / pr;
+    const double mean_vseg = (double) nnz / ((double) npanels * (double) (nseg ? nseg : 1));
+    if (p.panel_rows == 0 && npanels > 1 && mean_vseg < 8.0) return o;  // would shred the segments
+    o.panel_rows = pr;
+    return o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -161,9 +228,13 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     m_ = (uint32_t) R->rows; n_ = (uint32_t) R->cols; k_ = p->k; nnz_ = (uint64_t) R->nnz;
     prof_.enable(p->profile != 0 || p->schedule == 0);
 
-    const uint32_t tps = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : 0;
-    MFX_TRY(csc_.build(n_, nnz_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, tps, st_));
-    MFX_TRY(csr_.build(m_, nnz_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, tps, st_));
+    // wave-per-segment kernels (schedule 0, variant 0) walk the input-order arrays
+    const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
+    // CSC side gathers the float2 pack (u_prev, u_cur) by row; CSR side the float4 pack by column
+    MFX_TRY(csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space,
+                       choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), st_));
+    MFX_TRY(csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space,
+                       choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), st_));
 
     MFX_TRY(W_.alloc_zero((size_t) k_ * m_, st_));
     MFX_TRY(H_.alloc_zero((size_t) k_ * n_, st_));
@@ -398,9 +469,15 @@ int CcdSolver::get_factors(float* W, float* H, mfx_memspace space) {
 int CcdSolver::get_residual(float* csc_val, float* csr_val) {
     MFX_TRY(use_device(device_));
     MFX_TRY(flush_pending());
-    if (csc_val && nnz_) MFX_HIP(hipMemcpyAsync(csc_val, csc_.view.val, sizeof(float) * nnz_, hipMemcpyDeviceToHost, st_));
-    if (csr_val && nnz_) MFX_HIP(hipMemcpyAsync(csr_val, csr_.view.val, sizeof(float) * nnz_, hipMemcpyDeviceToHost, st_));
-    MFX_HIP(hipStreamSynchronize(st_));
+    DevBuf<float> tmp;  // residuals are stored panel-major: put them back in input order
+    MFX_TRY(tmp.alloc(nnz_ ? nnz_ : 1));
+    for (int side = 0; side < 2; ++side) {
+        float* out = side == 0 ? csc_val : csr_val;
+        if (!out || !nnz_) continue;
+        MFX_TRY(launch_unpermute(side == 0 ? csc_.view : csr_.view, tmp.get(), st_));
+        MFX_HIP(hipMemcpyAsync(out, tmp.get(), sizeof(float) * nnz_, hipMemcpyDeviceToHost, st_));
+        MFX_HIP(hipStreamSynchronize(st_));
+    }
     MFX_TRY(prof_.collect());
     return MFX_OK;
 }

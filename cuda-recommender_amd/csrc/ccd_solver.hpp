@@ -16,19 +16,26 @@ namespace mfx {
 // Owns one orientation's device arrays; `view` is what the kernels see.
 class SegStreamStore {
 public:
-    // ptr/idx/val live in `space`.  val may be nullptr (zeros).  tiles_per_span 0 = auto.
-    int build(uint32_t nseg, uint64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
-              mfx_memspace space, uint32_t tiles_per_span, hipStream_t st);
+    // ptr/idx/val live in `space` (input order).  val may be nullptr (zeros).  G = length of the
+    // gathered index space.  opt.panel_rows != 0 stores the non-zeros panel-major (flat_layout.hpp).
+    int build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx, const float* val,
+              mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st);
     SegStreamDev view;
     const FlatLayoutHost& layout() const { return layout_; }
 
 private:
     FlatLayoutHost layout_;
-    DevBuf<uint32_t> ptr_, idx_, seg_of_rank_, span_rank_base_;
+    DevBuf<uint32_t> ptr_, ptr_v_, seg_cnt_, idx_, seg_of_rank_, span_rank_base_, wg_panel_, perm_;
     DevBuf<float> val_, gpart_, hpart_, carry_g_, carry_h_;
     DevBuf<uint64_t> flags_;
     DevBuf<int32_t> rank_of_seg_;
+    DevBuf<uint16_t> idx16_;
 };
+
+// Panel size for an orientation whose largest LDS-staged pack element is `elem_bytes` wide:
+// 0 (plain layout) when panels are off or would shred the segments; see ccd_solver.hip.
+FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz, uint32_t G, uint32_t elem_bytes,
+                                bool need_plain);
 
 // Optional per-launch HIP-event bracketing (mfx_params.profile).  Events are recorded on the
 // solver's own stream -- the stream the kernels run on.

@@ -1,40 +1,116 @@
 #include "flat_layout.hpp"
 
 #include <algorithm>
+#include <thread>
 
 namespace mfx {
+namespace {
 
-static uint32_t pick_tiles_per_span(uint64_t nnz) {
+uint32_t pick_tiles_per_span(uint64_t nnz, bool panels) {
     // Aim for ~48k spans (256 CUs x 32 resident waves x ~6 rounds) but keep a span between
     // 2 and 16 tiles: shorter spans waste the per-span prologue, longer ones leave the tail of
-    // the grid unbalanced and lengthen nothing useful.
+    // the grid unbalanced.  With LDS panels a workgroup also pays one slice load per chunk, so
+    // spans are at least 8 tiles there.
     const uint64_t target_spans = 49152;
     uint64_t t = (nnz / kTileElems + target_spans - 1) / target_spans;
-    t = (t + 1) & ~uint64_t(1);  // the kernel consumes tiles in pairs
-    return (uint32_t) std::min<uint64_t>(16, std::max<uint64_t>(2, t));
+    t = (t + 1) & ~uint64_t(1);
+    const uint64_t lo = panels ? 8 : 2;
+    return (uint32_t) std::min<uint64_t>(16, std::max<uint64_t>(lo, t));
 }
 
-void build_flat_layout(const uint32_t* ptr, uint32_t nseg, uint64_t nnz, uint32_t tiles_per_span,
-                       FlatLayoutHost* out) {
+// Runs fn(begin, end) over [0, n) on a few host threads (plain std::thread: libmfx must not drag
+// a second OpenMP runtime into a process that already hosts torch's).
+template <typename F>
+void parallel_ranges(uint32_t n, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    if (n < 4096 || nt == 1) { fn(0u, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+        const uint32_t b = (uint32_t) ((uint64_t) n * t / nt), e = (uint32_t) ((uint64_t) n * (t + 1) / nt);
+        th.emplace_back([=] { fn(b, e); });
+    }
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, uint64_t nnz, uint32_t G,
+                       const FlatLayoutOptions& opt, FlatLayoutHost* out) {
     FlatLayoutHost& L = *out;
     L = FlatLayoutHost();
     L.nseg = nseg;
+    L.gather_len = G;
     L.nnz = nnz;
-    if (tiles_per_span == 0) tiles_per_span = pick_tiles_per_span(nnz);
-    if (tiles_per_span & 1) ++tiles_per_span;
-    L.tiles_per_span = tiles_per_span;
-    const uint64_t span = (uint64_t) tiles_per_span * kTileElems;
-    L.nspans = (uint32_t) std::max<uint64_t>(1, (nnz + span - 1) / span);
-    L.padded_nnz = (uint64_t) L.nspans * span;
+    L.panel_rows = opt.panel_rows;
+    L.npanels = opt.panel_rows ? std::max(1u, (G + opt.panel_rows - 1) / opt.panel_rows) : 1u;
+    L.spans_per_wg = opt.panel_rows ? std::max(1u, opt.spans_per_wg) : 1u;
+    uint32_t tps = opt.tiles_per_span ? opt.tiles_per_span : pick_tiles_per_span(nnz, opt.panel_rows != 0);
+    if (tps & 1) ++tps;  // the kernel consumes tiles in pairs
+    L.tiles_per_span = tps;
+    const uint64_t span = (uint64_t) tps * kTileElems;
+    const uint64_t chunk = span * L.spans_per_wg;
+    const uint32_t P = L.npanels, PR = L.panel_rows;
+    const size_t nv = (size_t) P * nseg;
+
+    // 1. entries per (panel, segment)
+    std::vector<uint32_t> cnt(nv, 0);
+    L.seg_cnt.resize(nseg);
+    parallel_ranges(nseg, [&](uint32_t b, uint32_t e) {
+        for (uint32_t c = b; c < e; ++c) {
+            L.seg_cnt[c] = ptr[c + 1] - ptr[c];
+            if (P == 1) { cnt[c] = ptr[c + 1] - ptr[c]; continue; }
+            for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) ++cnt[(size_t) (idx[q] / PR) * nseg + c];
+        }
+    });
+    // 2. panel-major exclusive scan; every panel padded to whole workgroup chunks, the padding
+    //    folded into the panel's last virtual segment
+    L.ptr_v.resize(nv + 1);
+    std::vector<uint64_t> panel_real_end(P);
+    uint64_t pos = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        for (uint32_t c = 0; c < nseg; ++c) {
+            L.ptr_v[(size_t) p * nseg + c] = (uint32_t) pos;
+            pos += cnt[(size_t) p * nseg + c];
+        }
+        panel_real_end[p] = pos;
+        pos = (pos + chunk - 1) / chunk * chunk;
+    }
+    if (pos == 0) pos = chunk;  // nnz == 0: keep one (all padding) chunk so that grids are never empty
+    L.ptr_v[nv] = (uint32_t) pos;
+    L.padded_nnz = pos;
+    L.nspans = (uint32_t) (pos / span);
+
+    // 3. stored order: panel-local indices + where every stored element came from
+    L.idx_local.assign(L.padded_nnz, L.pad_index());
+    L.perm.assign(L.padded_nnz, ~0u);
+    parallel_ranges(nseg, [&](uint32_t b, uint32_t e) {
+        std::vector<uint32_t> cur(P);
+        for (uint32_t c = b; c < e; ++c) {
+            if (ptr[c + 1] == ptr[c]) continue;
+            for (uint32_t p = 0; p < P; ++p) cur[p] = L.ptr_v[(size_t) p * nseg + c];
+            for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) {
+                const uint32_t p = P == 1 ? 0u : idx[q] / PR;
+                const uint32_t d = cur[p]++;
+                L.idx_local[d] = idx[q] - p * PR;
+                L.perm[d] = q;
+            }
+        }
+    });
+
+    // 4. head flags, ranks, span bases over the virtual segments
     L.flags.assign(L.padded_nnz / 64, 0);
-    L.rank_of_seg.assign(nseg, -1);
+    L.rank_of_seg.assign(nv, -1);
     L.seg_of_rank.clear();
-    L.seg_of_rank.reserve(nseg);
-    for (uint32_t c = 0; c < nseg; ++c) {
-        if (ptr[c + 1] > ptr[c]) {
-            L.rank_of_seg[c] = (int32_t) L.seg_of_rank.size();
-            L.seg_of_rank.push_back(c);
-            const uint64_t head = ptr[c];
+    L.seg_of_rank.reserve(std::min<size_t>(nv, (size_t) nnz + P));
+    std::vector<uint32_t> head_pos;
+    head_pos.reserve(L.seg_of_rank.capacity());
+    for (size_t v = 0; v < nv; ++v) {
+        if (L.ptr_v[v + 1] > L.ptr_v[v]) {
+            L.rank_of_seg[v] = (int32_t) L.seg_of_rank.size();
+            L.seg_of_rank.push_back((uint32_t) (v % nseg));
+            const uint64_t head = L.ptr_v[v];
+            head_pos.push_back((uint32_t) head);
             L.flags[head >> 6] |= uint64_t(1) << (head & 63);
         }
     }
@@ -43,8 +119,19 @@ void build_flat_layout(const uint32_t* ptr, uint32_t nseg, uint64_t nnz, uint32_
     uint32_t r = 0;
     for (uint32_t s = 0; s < L.nspans; ++s) {
         const uint64_t start = (uint64_t) s * span;
-        while (r < L.nne && ptr[L.seg_of_rank[r]] < start) ++r;
+        while (r < L.nne && head_pos[r] < start) ++r;
         L.span_rank_base[s] = r;  // heads strictly before the span's first element
+    }
+    // 5. workgroup -> panel
+    if (PR) {
+        const uint32_t nwg = L.nspans / L.spans_per_wg;
+        L.wg_panel.assign(nwg, 0);
+        uint32_t p = 0;
+        for (uint32_t w = 0; w < nwg; ++w) {
+            const uint64_t start = (uint64_t) w * chunk;
+            while (p + 1 < P && start >= L.ptr_v[(size_t) (p + 1) * nseg]) ++p;
+            L.wg_panel[w] = p;
+        }
     }
 }
 

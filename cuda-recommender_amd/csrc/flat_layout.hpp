@@ -1,20 +1,32 @@
 // flat_layout.hpp -- static metadata that lets one kernel stream a CSR/CSC orientation as a flat,
-// nnz-balanced array while still reducing per segment (row or column).
+// nnz-balanced array while still reducing per segment (row or column), with the gathered factor
+// entries served from LDS.
 //
-// The sparsity pattern never changes during a solve, so everything that depends only on `ptr`
-// is computed once, on the host, at solver creation:
+// The sparsity pattern never changes during a solve, so everything that depends only on the
+// pattern is computed once, on the host, at solver creation:
 //
-//   span            a fixed run of L = 256 * tiles_per_span consecutive non-zeros, owned by one
-//                   wavefront (64 lanes x 4 consecutive non-zeros per tile, 16-byte loads)
-//   head flag       1 bit per non-zero: "first entry of its segment" (0.125 B/nnz of extra reads,
-//                   against 4 B/nnz for an explicit per-nnz segment id)
-//   rank            index of a segment among the NON-EMPTY segments; element -> rank is a popcount
-//   span_rank_base  number of heads before the span's first element
+//   panel           the gathered index space [0, G) is cut into panels of `panel_rows` entries so
+//                   that one panel's slice of the operand pack fits in LDS.  Non-zeros are stored
+//                   PANEL-MAJOR: all entries whose gathered index falls in panel 0 (ordered by
+//                   segment, then in the input's order), then panel 1, ...  Stored indices are
+//                   panel-local.  npanels == 1 and panel_rows == 0 is the plain layout (global
+//                   gather, input order).
+//   virtual segment (panel p, segment c) -> v = p * nseg + c; ptr_v[v] .. ptr_v[v+1] in the padded
+//                   panel-major coordinates.  Every panel is padded to a whole number of
+//                   workgroup chunks; the padding is folded into the panel's last virtual segment
+//                   and points at a zero slot (LDS index panel_rows), so it contributes nothing.
+//   span            L = 256 * tiles_per_span consecutive stored non-zeros, owned by one wavefront
+//                   (64 lanes x 4 consecutive non-zeros per tile, 16-byte loads); a workgroup
+//                   chunk is spans_per_wg consecutive spans of ONE panel.
+//   head flag       1 bit per stored non-zero: "first entry of its virtual segment"
+//   rank            index of a virtual segment among the NON-EMPTY ones; element -> rank is a
+//                   popcount of head flags.  span_rank_base = heads before the span.
 //
-// Reduction contract (kernels in ccd_kernels.hip): the span that contains a segment's head stores
-// that segment's partial sum to part[rank] (exactly one writer, plain store); a span whose first
-// element is NOT a head stores the sum of its leading run to carry[span].  finalize adds, in span
-// order, the carries of spans s with  ptr[c]/L < s <= (ptr[c+1]-1)/L  -- deterministic, no atomics.
+// Reduction contract (ccd_kernels.hip): the span that contains a virtual segment's head stores that
+// segment's partial sum to part[rank] (exactly one writer, plain store); a span whose first element
+// is NOT a head stores the sum of its leading run to carry[span].  finalize adds, for segment c,
+// over panels p in order: part[rank(p,c)] + carries of spans s with
+// ptr_v[v]/L < s <= (ptr_v[v+1]-1)/L -- deterministic, no atomics.
 #pragma once
 
 #include <cstdint>
@@ -25,21 +37,37 @@ namespace mfx {
 constexpr uint32_t kTileElems = 256;  // 64 lanes x 4 elements
 
 struct FlatLayoutHost {
-    uint32_t nseg = 0;            // segments (columns for CSC, rows for CSR)
-    uint32_t nne = 0;             // non-empty segments
-    uint32_t nspans = 0;          // wave spans
-    uint32_t tiles_per_span = 0;  // span length / 256
-    uint64_t nnz = 0;
-    uint64_t padded_nnz = 0;      // nspans * span length (idx/val/flags are allocated to this)
+    uint32_t nseg = 0;            // real segments (columns for CSC, rows for CSR)
+    uint32_t gather_len = 0;      // G: length of the gathered index space
+    uint32_t npanels = 1;
+    uint32_t panel_rows = 0;      // 0: plain layout (no LDS staging)
+    uint32_t spans_per_wg = 1;
+    uint32_t nne = 0;             // non-empty virtual segments
+    uint32_t nspans = 0;
+    uint32_t tiles_per_span = 0;
+    uint64_t nnz = 0;             // real non-zeros
+    uint64_t padded_nnz = 0;      // stored elements (nspans * span length)
+    std::vector<uint32_t> ptr_v;           // [npanels*nseg + 1]
+    std::vector<uint32_t> seg_cnt;         // [nseg] real entries per segment
     std::vector<uint64_t> flags;           // [padded_nnz / 64]
-    std::vector<int32_t> rank_of_seg;      // [nseg], -1 for an empty segment
-    std::vector<uint32_t> seg_of_rank;     // [nne]
+    std::vector<int32_t> rank_of_seg;      // [npanels*nseg], -1 for an empty virtual segment
+    std::vector<uint32_t> seg_of_rank;     // [nne] REAL segment id of each rank
     std::vector<uint32_t> span_rank_base;  // [nspans]
+    std::vector<uint32_t> wg_panel;        // [nspans / spans_per_wg] (panel layout only)
+    std::vector<uint32_t> idx_local;       // [padded_nnz] panel-local gathered index (pad: zero slot)
+    std::vector<uint32_t> perm;            // [padded_nnz] input position of each stored element, ~0u for pad
     uint32_t span_len() const { return tiles_per_span * kTileElems; }
+    uint32_t pad_index() const { return panel_rows ? panel_rows : 0u; }
 };
 
-// tiles_per_span = 0 picks one from nnz (enough spans to fill 256 CUs several times over).
-void build_flat_layout(const uint32_t* ptr, uint32_t nseg, uint64_t nnz, uint32_t tiles_per_span,
-                       FlatLayoutHost* out);
+struct FlatLayoutOptions {
+    uint32_t tiles_per_span = 0;  // 0: choose
+    uint32_t panel_rows = 0;      // 0: plain layout
+    uint32_t spans_per_wg = 1;    // waves per workgroup in the panel kernel
+};
+
+// ptr/idx are the input orientation (host pointers); G is the gathered dimension.
+void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, uint64_t nnz, uint32_t G,
+                       const FlatLayoutOptions& opt, FlatLayoutHost* out);
 
 }  // namespace mfx

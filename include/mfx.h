@@ -82,7 +82,11 @@ typedef struct mfx_params {
     int32_t kernel_variant;    /* schedule 0 only: 0 = wave-per-segment kernels, 1 = flat-stream */
     int32_t profile;           /* 1: bracket every launch with HIP events (mfx_*_kernel_times) */
     int32_t tiles_per_span;    /* flat-stream span length / 256; 0 = choose from nnz */
-    int32_t reserved[4];
+    int32_t panel_rows;        /* LDS panels: gathered entries staged per workgroup. 0 = choose (64 KB of
+                                  LDS per workgroup when segments stay long enough), -1 = off (gather from
+                                  L2), > 0 = explicit */
+    int32_t wg_waves;          /* wavefronts per workgroup of the panel kernel: 4, 8 or 16; 0 = 16 */
+    int32_t reserved[2];
 } mfx_params;
 
 /* One outer iteration's numbers == the fields of the reference's log line
@@ -167,7 +171,9 @@ int mfx_als_destroy(mfx_als_t s);
  * ---------------------------------------------------------------------------------- */
 /* RankOneUpdate_v_kernel / _u_kernel (cuda_src/CCD_CUDA.cu:24-58) == the sweep of
  * src/CCD.cpp:110-113: out[c] = sum(vec[idx]*val) / (lambda*|Omega_c| + sum(vec[idx]^2)),
- * 0 for an empty segment.  variant: 0 = wave-per-segment kernel, 1 = flat-stream kernel. */
+ * 0 for an empty segment.  variant: 0 = wave-per-segment kernel, 1 = flat-stream kernel gathering
+ * from L2, 2 = flat-stream kernel with LDS panels (size chosen), >= 16 = LDS panels of `variant`
+ * gathered entries (test hook: forces many panels on small inputs). */
 int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx,
                        const float* val, int64_t vec_len, const float* vec, float lambda,
                        float* out, int variant, int device);

@@ -1,0 +1,107 @@
+// layout_emulator.cpp -- CPU check of the flat/panel layout metadata and of the reduction
+// contract the GPU kernels implement (flat_layout.hpp): builds layouts for random patterns,
+// replays the per-span walk (head flags, ranks, part[] / carry[] ownership) element by element
+// and checks that finalize's recombination gives every segment's exact integer sum.
+// Built and run by tests/test_layout_cpu.py (no GPU needed).
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "flat_layout.hpp"
+
+using namespace mfx;
+
+static int check(uint32_t nseg, uint32_t G, const std::vector<uint32_t>& lens, const FlatLayoutOptions& opt,
+                 std::mt19937& rng) {
+    std::vector<uint32_t> ptr(nseg + 1, 0);
+    for (uint32_t c = 0; c < nseg; ++c) ptr[c + 1] = ptr[c] + lens[c];
+    const uint64_t nnz = ptr[nseg];
+    std::vector<uint32_t> idx(nnz);
+    std::vector<long long> val(nnz), vec(G);
+    for (auto& x : idx) x = rng() % G;
+    for (auto& x : val) x = (long long) (rng() % 7) - 3;
+    for (auto& x : vec) x = (long long) (rng() % 5) - 2;
+    FlatLayoutHost L;
+    build_flat_layout(ptr.data(), idx.data(), nseg, nnz, G, opt, &L);
+    const uint32_t span = L.span_len();
+    if (L.padded_nnz % span || L.nspans != L.padded_nnz / span) { printf("span accounting\n"); return 1; }
+    if (opt.panel_rows && (L.nspans % L.spans_per_wg)) { printf("wg accounting\n"); return 1; }
+    // every input position appears exactly once; stored index maps back to the input index
+    std::vector<char> seen(nnz, 0);
+    for (uint64_t e = 0; e < L.padded_nnz; ++e) {
+        const uint32_t q = L.perm[e];
+        if (q == ~0u) { if (L.idx_local[e] != L.pad_index()) { printf("pad index\n"); return 1; } continue; }
+        if (q >= nnz || seen[q]) { printf("perm not a bijection\n"); return 1; }
+        seen[q] = 1;
+        uint32_t panel = 0;
+        if (opt.panel_rows) {
+            panel = L.wg_panel[e / ((uint64_t) span * L.spans_per_wg)];
+            if (L.idx_local[e] >= L.panel_rows) { printf("local index out of panel\n"); return 1; }
+        }
+        if (panel * L.panel_rows + L.idx_local[e] != idx[q]) { printf("index mapping\n"); return 1; }
+    }
+    for (uint64_t q = 0; q < nnz; ++q) if (!seen[q]) { printf("missing element\n"); return 1; }
+    // replay the kernel's span walk
+    std::vector<long long> part(L.nne ? L.nne : 1, -777), carry(L.nspans, -777);
+    for (uint32_t s = 0; s < L.nspans; ++s) {
+        const int rank_base = (int) L.span_rank_base[s];
+        int cur = rank_base - 1;
+        long long acc = 0;
+        for (uint64_t e = (uint64_t) s * span; e < (uint64_t) (s + 1) * span; ++e) {
+            if ((L.flags[e >> 6] >> (e & 63)) & 1) {
+                if (cur >= rank_base) part[cur] = acc; else carry[s] = acc;
+                ++cur;
+                acc = 0;
+            }
+            const uint32_t q = L.perm[e];
+            if (q != ~0u) acc += vec[idx[q]] * val[q];
+        }
+        if (cur >= rank_base) part[cur] = acc; else carry[s] = acc;
+    }
+    // finalize's recombination
+    for (uint32_t c = 0; c < nseg; ++c) {
+        long long ref = 0;
+        for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) ref += vec[idx[q]] * val[q];
+        long long got = 0;
+        for (uint32_t p = 0; p < L.npanels; ++p) {
+            const size_t v = (size_t) p * nseg + c;
+            const int r = L.rank_of_seg[v];
+            if (r < 0) continue;
+            if (L.seg_of_rank[r] != c) { printf("seg_of_rank\n"); return 1; }
+            got += part[r];
+            const uint32_t lo = L.ptr_v[v], hi = L.ptr_v[v + 1];
+            for (uint32_t s = lo / span + 1; s <= (hi - 1) / span; ++s) got += carry[s];
+        }
+        if (got != ref || L.seg_cnt[c] != lens[c]) { printf("segment %u: got %lld want %lld\n", c, got, ref); return 1; }
+    }
+    return 0;
+}
+
+int main() {
+    std::mt19937 rng(12345);
+    int cases = 0;
+    for (int trial = 0; trial < 24; ++trial) {
+        const uint32_t nseg = 1 + rng() % 400, G = 1 + rng() % 3000;
+        std::vector<uint32_t> lens(nseg);
+        for (auto& l : lens) {
+            const uint32_t k = rng() % 10;
+            l = k < 3 ? 0 : k < 7 ? rng() % 6 : k < 9 ? rng() % 300 : rng() % 9000;
+        }
+        if (trial % 7 == 0) for (auto& l : lens) l = 0;  // nnz == 0
+        for (uint32_t tps : {2u, 4u, 16u}) {
+            for (uint32_t pr : {0u, 1u, 7u, 64u, 1000u, 5000u}) {
+                for (uint32_t wg : {4u, 8u, 16u}) {
+                    if (pr == 0 && wg != 4) continue;
+                    FlatLayoutOptions o;
+                    o.tiles_per_span = tps; o.panel_rows = pr ? (pr > G ? G : pr) : 0; o.spans_per_wg = wg;
+                    if (pr && (uint64_t) ((G + o.panel_rows - 1) / o.panel_rows) * tps * 256 * wg > 40000000ull) continue;
+                    if (check(nseg, G, lens, o, rng)) { printf("FAILED trial %d tps %u pr %u wg %u\n", trial, tps, pr, wg); return 1; }
+                    ++cases;
+                }
+            }
+        }
+    }
+    printf("layout emulator: %d cases ok\n", cases);
+    return 0;
+}

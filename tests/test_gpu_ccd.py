@@ -41,7 +41,10 @@ def relerr(a, b):
 
 
 # ------------------------------------------------------------------ single operators
-@pytest.mark.parametrize("variant", [0, 1])
+OP_VARIANTS = [0, 1, 2, 16, 100]  # wave-per-segment, flat/L2 gather, flat/LDS auto, LDS panels of 16 / 100 entries
+
+
+@pytest.mark.parametrize("variant", OP_VARIANTS)
 @pytest.mark.parametrize("name", CASES)
 def test_update_rating_bit_exact_golden(mfx, name, variant):
     g, d = load_golden(name)
@@ -59,7 +62,7 @@ def test_update_rating_bit_exact_golden(mfx, name, variant):
     assert np.array_equal(bits(csr), bits(g["step_csr_add"]))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", OP_VARIANTS)
 @pytest.mark.parametrize("name", CASES)
 def test_rank_one_sweep_golden(mfx, name, variant):
     g, d = load_golden(name)
@@ -72,7 +75,7 @@ def test_rank_one_sweep_golden(mfx, name, variant):
     assert relerr(u1, g["step_u1"]) < 2e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 1000])
 def test_single_ops_medium(mfx, orc, medium, variant):
     d = medium
     rng = np.random.default_rng(3)
@@ -102,14 +105,16 @@ def test_flat_kernel_long_and_degenerate_segments(mfx, orc):
     vec = rng.uniform(-1, 1, nvec).astype(np.float32)
     ref = orc.rank_one_sweep(ptr, idx, val, vec, 0.1, 2)
     # (explicit span lengths are exercised through the resident solver: test_ccdpp_ml1m_shape_vs_oracle)
-    out = mfx.rank_one_sweep(ptr, idx, val, vec, 0.1, 1)
-    assert relerr(out, ref) < 2e-5
-    assert np.all(out[lens == 0] == 0)
     per_seg = rng.uniform(-1, 1, lens.size).astype(np.float32)
-    a, b = val.copy(), val.copy()
+    a = val.copy()
     orc.update_rating(ptr, idx, a, vec, per_seg, True, 2)
-    mfx.update_rating(ptr, idx, b, vec, per_seg, True, 1)
-    assert np.array_equal(bits(a), bits(b))
+    for variant in (1, 2, 16, 333):  # 333-entry panels: 16 panels, most of them cutting the long segment
+        out = mfx.rank_one_sweep(ptr, idx, val, vec, 0.1, variant)
+        assert relerr(out, ref) < 2e-5, variant
+        assert np.all(out[lens == 0] == 0)
+        b = val.copy()
+        mfx.update_rating(ptr, idx, b, vec, per_seg, True, variant)
+        assert np.array_equal(bits(a), bits(b)), variant
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -125,27 +130,31 @@ def test_test_rmse_matches_calrmse(mfx, orc, name):
 
 
 # ------------------------------------------------------------------ whole solves, golden
-def _params(mfx, k, lam, t, T, schedule, variant, tiles=0):
+def _params(mfx, k, lam, t, T, schedule, variant, tiles=0, panel_rows=0, wg_waves=0):
     p = mfx.parameter()
     p.k, p.lambda_, p.maxiter, p.maxinneriter = k, lam, t, T
     p.schedule, p.kernel_variant, p.tiles_per_span = schedule, variant, tiles
+    p.panel_rows, p.wg_waves = panel_rows, wg_waves
     return p
 
 
-SCHEDULES = [(1, 1), (0, 0), (0, 1)]  # (schedule, kernel_variant): fused, as-written wave, as-written flat
+# (schedule, kernel_variant, panel_rows): fused with LDS panels (auto = one panel here), fused with
+# tiny panels (many panels per matrix), fused gathering from L2, as-written wave, as-written flat
+SCHEDULES = [(1, 1, 0), (1, 1, 24), (1, 1, -1), (0, 0, 0), (0, 1, 0), (0, 1, 24)]
 
 
-@pytest.mark.parametrize("schedule,variant", SCHEDULES)
+@pytest.mark.parametrize("schedule,variant,panel_rows", SCHEDULES)
 @pytest.mark.parametrize("tag", ["ccd_T1", "ccd_T3"])
 @pytest.mark.parametrize("name", CASES)
-def test_ccdpp_matches_reference_golden(mfx, name, tag, schedule, variant):
+def test_ccdpp_matches_reference_golden(mfx, name, tag, schedule, variant, panel_rows):
     """kernel_wrapper_ccdpp_NV vs the reference's own ccdr1_OMP output (tests/golden)."""
     g, d = load_golden(name)
     k, lam = int(g["k"][0]), float(g["lam"][0])
     t, T = int(g[tag + "__maxiter"][0]), int(g[tag + "__maxinner"][0])
     W = np.array(g[tag + "__W0"], np.float32, copy=True)
     H = np.array(g[tag + "__H0"], np.float32, copy=True)  # content must be ignored (H starts at 0)
-    reports = mfx.kernel_wrapper_ccdpp_NV(d, mfx.test_data_of(d), W, H, _params(mfx, k, lam, t, T, schedule, variant))
+    reports = mfx.kernel_wrapper_ccdpp_NV(d, mfx.test_data_of(d), W, H,
+                                          _params(mfx, k, lam, t, T, schedule, variant, panel_rows=panel_rows))
     assert mfx.kernel_wrapper_ccdpp_NV.last_status == 0
     assert relerr(W, g[tag + "__W"]) < 2e-3 and relerr(H, g[tag + "__H"]) < 2e-3
     rmse = np.array([r.rmse for r in reports])
@@ -154,13 +163,13 @@ def test_ccdpp_matches_reference_golden(mfx, name, tag, schedule, variant):
     assert abs(mfx.calculate_rmse_directly(W, H, mfx.test_data_of(d), k, False, quiet=True) - float(g[tag + "__final_rmse"][0])) < 1e-4
 
 
-@pytest.mark.parametrize("schedule,variant", SCHEDULES)
+@pytest.mark.parametrize("schedule,variant,panel_rows", SCHEDULES)
 @pytest.mark.parametrize("name", CASES)
-def test_residual_state_matches_reference(mfx, name, schedule, variant):
+def test_residual_state_matches_reference(mfx, name, schedule, variant, panel_rows):
     """After the run both residual copies equal the reference's mutated csc/csr value arrays."""
     g, d = load_golden(name)
     k, lam = int(g["k"][0]), float(g["lam"][0])
-    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, 3, 1, schedule, variant))
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, 3, 1, schedule, variant, panel_rows=panel_rows))
     s.set_factors(np.ascontiguousarray(g["ccd_T1__W0"]))
     s.iterate(3)
     csc, csr = s.get_residual(d.nnz)
@@ -170,12 +179,14 @@ def test_residual_state_matches_reference(mfx, name, schedule, variant):
 
 
 # ------------------------------------------------------------------ whole solves, ML-1M shape
-@pytest.mark.parametrize("schedule,variant,tiles", [(1, 1, 0), (1, 1, 2), (1, 1, 16), (0, 0, 0), (0, 1, 4)])
-def test_ccdpp_ml1m_shape_vs_oracle(mfx, orc, medium, schedule, variant, tiles):
+@pytest.mark.parametrize("schedule,variant,tiles,panel_rows,wg_waves", [
+    (1, 1, 0, 0, 0), (1, 1, 2, 1000, 4), (1, 1, 16, 500, 16), (1, 1, 4, -1, 0), (1, 1, 8, 2048, 8),
+    (0, 0, 0, 0, 0), (0, 1, 4, 700, 8)])
+def test_ccdpp_ml1m_shape_vs_oracle(mfx, orc, medium, schedule, variant, tiles, panel_rows, wg_waves):
     d, k, lam, t = medium, 40, 0.05, 3
     W0 = mfx.initial_col(k, d.rows)
     Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, 1, orc.max_threads())
-    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, 1, schedule, variant, tiles))
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, 1, schedule, variant, tiles, panel_rows, wg_waves))
     s.set_factors(W0.copy())
     reports = s.iterate(t)
     W, H = s.get_factors()

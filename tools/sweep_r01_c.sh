@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+run() { name=$1; shift; timeout -k 10 200 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/sw_$name.log 2>&1; python3 - <<PY
+import json
+try:
+    l=[x for x in open('gpurun_out/sw_$name.log') if x.startswith('{')][-1]; j=json.loads(l)
+    print('$name', j['ms_per_step'], 'ms', {k:v['avg_us'] for k,v in j['kernels'].items()}, 'rmse', j['test_rmse_after'])
+except Exception as e: print('$name FAILED', e)
+PY
+}
+for d in 0 1 2 4 6; do MFX_DBG=$d run dbg$d; done
+for d in 0 1 6; do MFX_DBG=$d run w16_dbg$d --wg-waves 16; done
