@@ -32,6 +32,26 @@ for _p in (ROOT, os.path.join(ROOT, "cuda-recommender_amd")):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
+def host_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +156,10 @@ def main() -> None:
         "ccd_wave_sweep": 8.0 * Z + 4.0 * (m + n) + 8.0 * min(m, n),
         "ccd_wave_resid": 12.0 * Z + 4.0 * (m + n),
     }
+    # bytes the LDS-panel kernels physically stream per non-zero: 16-bit local index + fp32 value read
+    # + fp32 value written (the contract figure above keeps SURVEY 8d's 32-bit index)
+    phys = {"ccd_fused_csc_pass": 10.0 * Z + 2 * flags, "ccd_fused_csr_pass": 10.0 * Z + 2 * flags,
+            "ccd_flat_sweep": 6.0 * Z + 2 * flags, "ccd_flat_resid": 10.0 * Z + 2 * flags}
     roofline = None
     dom = None
     if ktimes:
@@ -159,6 +183,7 @@ def main() -> None:
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
                         "algorithmic_bytes_per_launch": int(alg[dom]),
+                        "streamed_bytes_per_launch": int(phys[dom]) if (a.panel_rows >= 0 and dom in phys) else int(alg[dom]),
                         "as_written_equiv_frac": round(a.k * (48 + 16 * a.inner) * nnz_global /
                                                        (elapsed / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
     kernels = {kn: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1]),
@@ -172,7 +197,7 @@ def main() -> None:
     if world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as orc
         host = synth_torch.to_rating_data(d)
-        threads = orc.max_threads()
+        threads = min(orc.max_threads(), host_cores())
         ks = max(1, min(a.cpu_ranks, a.k))
         Wc = np.ascontiguousarray(W0[:ks])
         _, _, _, times, _, _ = orc.ccdr1(host, Wc, ks, a.lam, 2, a.inner, threads)

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         if (cur >= 0) pcur = fetch_ps(cur);
     }
     float og = 0.f, oh = 0.f;  // per-lane sums of the open segment since its last head
+    bool open_spread = false;  // wave-uniform: og/oh hold per-lane partials (else only lane 0 is non-zero)
 
     // panel-local indices are 16-bit: 2 B/nnz instead of 4 (10 B/nnz per fused pass instead of 12)
     using IdxVec = typename std::conditional<LDS, u16x4, u32x4>::type;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                 if (partial && e0 + e >= a.nnz) { gc[e] = 0.f; hc[e] = 0.f; }
                 if constexpr (TR::kDot) { og += gc[e]; oh += hc[e]; }
             }
+            open_spread = true;
         } else {
             // ---- segmented tile ----
             const uint32_t wsel = lane >> 4;
@@ -319,7 +321,15 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
             }
             if (TR::kDot && !(a.dbg & 4)) {
                 // carry-in: the open segment's sum so far, as a wave-uniform value
-                const float cin_g = wave_sum(og), cin_h = wave_sum(oh);
+                float cin_g, cin_h;
+                if (open_spread) {
+                    cin_g = wave_sum(og);
+                    cin_h = wave_sum(oh);
+                } else {  // after a segmented tile the open sum sits in lane 0
+                    cin_g = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, og)));
+                    cin_h = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oh)));
+                }
+                open_spread = false;
                 // lane-serial pass: fg/fh = run before the lane's first head, ag/ah = run after its
                 // last head; runs between two heads of the same lane are complete segments.
                 float ag = 0.f, ah = 0.f, fg = 0.f, fh = 0.f;
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         }
     }
     if constexpr (TR::kDot) {
-        const float tg = wave_sum(og), th = wave_sum(oh);
+        const float tg = open_spread ? wave_sum(og) : og, th = open_spread ? wave_sum(oh) : oh;
         if (lane == 0) {
             if (cur >= rank_base) {  // the open segment's head lies in this span: we own its slot
                 a.gpart[cur] = tg;

@@ -450,7 +450,7 @@ int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
 }
 
 int CcdSolver::set_profile(bool on) {
-    MFX_REQUIRE(p_.schedule != 0 || on, "schedule 0 derives its rank/update split from the launch events");
+    // (schedule 0 keeps its launch events on regardless: its rank/update split is derived from them)
     p_.profile = on ? 1 : 0;
     prof_.enable(on || p_.schedule == 0);
     prof_.reset_totals();

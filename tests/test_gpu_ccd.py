@@ -243,3 +243,19 @@ def test_errors_are_reported_not_fatal(mfx, medium):
     p.device = 99
     with pytest.raises(mfx.MfxError, match="device"):
         mfx.CcdSolver(medium, None, p)
+
+
+def test_sharded_path_single_rank_rccl(mfx, medium):
+    """The multi-GPU code path (combine -> RCCL all-reduce -> finalize from the reduced buffer, fp64
+    all-reduce of the squared error) with a 1-rank communicator must reproduce the unsharded solve."""
+    d, k = medium, 8
+    W0 = mfx.initial_col(k, d.rows)
+    s0 = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, 0.05, 2, 2, 1, 1))
+    s0.set_factors(W0.copy()); r0 = s0.iterate(2); f0 = s0.get_factors(); s0.close()
+    comm = mfx.Comm(mfx.Comm.unique_id(), 0, 1, 0)
+    cnt = np.ascontiguousarray(np.diff(d.csc_col_ptr.astype(np.int64)).astype(np.uint32))
+    s1 = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, 0.05, 2, 2, 1, 1), comm=comm, global_col_nnz=cnt,
+                       global_test_nnz=d.nnz_test)
+    s1.set_factors(W0.copy()); r1 = s1.iterate(2); f1 = s1.get_factors(); s1.close(); comm.close()
+    assert np.array_equal(bits(f0[0]), bits(f1[0])) and np.array_equal(bits(f0[1]), bits(f1[1]))
+    assert [r.rmse for r in r0] == [r.rmse for r in r1]

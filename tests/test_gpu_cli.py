@@ -1,0 +1,39 @@
+"""GPU test of the mfx_train driver: the reference's command line end to end on a golden dataset."""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("solver", ["ccd", "als"])
+def test_mfx_train_matches_reference_log(tmp_path, solver):
+    import mfx
+    g, d = load_golden("small")
+    mfx.dataset.write_dataset_dir(str(tmp_path / "ds"), d)
+    exe = os.path.join(ROOT, "cuda-recommender_amd", "mfx_train")
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    tag = "ccd_T1" if solver == "ccd" else "als"
+    args = [exe, "-CUDA", "-k", str(k), "-l", repr(lam), "-t", str(int(g[tag + "__maxiter"][0])), "-T", "1",
+            "-save", str(tmp_path / "model.bin")] + (["-ALS"] if solver == "als" else []) + [str(tmp_path / "ds")]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rmse = np.array([float(x) for x in re.findall(r"\[-INFO-\] iteration num \d+ .*RMSE=([0-9.]+)", r.stdout)])
+    assert np.all(np.abs(rmse - g[tag + "__rmse"]) < 1e-4), (rmse, g[tag + "__rmse"])
+    final = float(re.search(r"Test RMSE = ([0-9.]+)\.", r.stdout).group(1))
+    assert abs(final - float(g[tag + "__final_rmse"][0])) < 1e-4
+    # model file = save_mat_t(W) then save_mat_t(H)
+    raw = open(tmp_path / "model.bin", "rb").read()
+    m, n = struct.unpack("<qq", raw[:16])
+    W = np.frombuffer(raw[16:16 + 4 * m * n], np.float32).reshape(m, n)
+    ref = g[tag + "__W"] if solver == "als" else g[tag + "__W"]  # als: rows x k row-major; ccd: k x rows stored transposed
+    if solver == "ccd":
+        assert (m, n) == (d.rows, k)
+        W = W.T
+    assert np.max(np.abs(W - ref)) < 5e-3 * np.max(np.abs(ref))

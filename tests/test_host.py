@@ -138,3 +138,47 @@ def test_golden_compare_and_rmse_helpers(mfx):
     assert mfx.golden_compare(W2, W, k, d.rows, quiet=True) == 2
     r = mfx.calculate_rmse_directly(W, H, mfx.test_data_of(d), k, False, quiet=True)
     assert abs(r - float(g["ccd_T1__final_rmse"][0])) < 5.1e-7
+
+
+def _run_cli(args, cwd=None):
+    import subprocess
+    exe = os.path.join(ROOT, "cuda-recommender_amd", "mfx_train")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "cuda-recommender_amd"), "cli"], check=True, capture_output=True)
+    return subprocess.run([exe] + args, capture_output=True, text=True, cwd=cwd, timeout=300)
+
+
+def test_cli_usage_and_loader(mfx, tmp_path):
+    """mfx_train keeps the reference's flags, help text and load() messages (src/extras.cpp:46-141)."""
+    r = _run_cli([])
+    assert r.returncode != 0 and "Usage: omp-pmf-train [options] data_dir [model_filename]" in r.stdout
+    assert "-ALS: Flag to enable ALS algorithm" in r.stdout
+    assert _run_cli(["-CUDA"]).returncode != 0  # valueless flag as last argv -> usage, like the reference
+    r = _run_cli([str(tmp_path / "nope")])
+    assert r.returncode != 0 and "Can't open meta input file." in r.stdout
+    g, d = load_golden("tiny")
+    mfx.dataset.write_dataset_dir(str(tmp_path / "ds"), d)
+    r = _run_cli(["-k", "8", "-t", "2", str(tmp_path / "ds")])  # neither -CUDA nor -OMP: load, init, validate
+    assert r.returncode == 0, r.stderr
+    assert "[info] Picked Version: CCD!" in r.stdout and "K = 8 | InnerIter = 1 | OuterIter = 2" in r.stdout
+    assert r.stdout.count("Check... PASS!") == 2  # untouched copies compare equal
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_cli_gpu_path_fails_loudly_without_gpu(mfx, tmp_path):
+    g, d = load_golden("tiny")
+    mfx.dataset.write_dataset_dir(str(tmp_path / "ds"), d)
+    r = _run_cli(["-CUDA", "-k", "8", str(tmp_path / "ds")])
+    assert "CCD FAILED: no usable HIP device" in r.stderr  # printed, process continues (CCD_CUDA.cu:174-176)
+    assert "[info] CUDA Training time:" in r.stdout
+
+
+def test_model_file_format_roundtrip(tmp_path):
+    """save_mat_t layout: [long m][long n][m*n float32 row-major] (src/tools.cpp:90-118)."""
+    import struct
+    W = np.arange(12, dtype=np.float32).reshape(3, 4)
+    with open(tmp_path / "m.bin", "wb") as f:
+        f.write(struct.pack("<qq", 3, 4)); f.write(W.tobytes())
+    raw = open(tmp_path / "m.bin", "rb").read()
+    m, n = struct.unpack("<qq", raw[:16])
+    assert (m, n) == (3, 4) and np.array_equal(np.frombuffer(raw[16:], np.float32).reshape(3, 4), W)
