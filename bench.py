@@ -197,7 +197,7 @@ def main() -> None:
     if world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as orc
         host = synth_torch.to_rating_data(d)
-        threads = min(orc.max_threads(), host_cores())
+        threads = orc.max_threads()  # min(OpenMP max, cgroup/affinity share of this box, 32)
         ks = max(1, min(a.cpu_ranks, a.k))
         Wc = np.ascontiguousarray(W0[:ks])
         _, _, _, times, _, _ = orc.ccdr1(host, Wc, ks, a.lam, 2, a.inner, threads)

@@ -234,12 +234,12 @@ int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipS
     AlsArgs a = base;
     if (nitems) {
         a.count = nitems;
-        hipLaunchKernelGGL(k_als_gram<NT>, dim3(nitems), dim3(64), lds_bytes, st, a);
+        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_gram<NT>, dim3(nitems), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     if (nreduces) {
         a.count = nreduces;
-        hipLaunchKernelGGL(k_als_reduce<NT>, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_reduce<NT>, dim3(nreduces), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     return MFX_OK;

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(kBlock) void k_resid_wave(uint32_t nseg, const uint
 struct FlatArgs {
     const void* idx;  // uint32 (plain layout) or uint16 panel-local (LDS panels)
     float* val;
-    const uint64_t* flags;
+    const uint32_t* flags32;
+    const uint32_t* hpre;
     const uint32_t* seg_of_rank;
-    const uint32_t* span_rank_base;
     const uint32_t* wg_panel;
     uint32_t nspans;
     uint32_t tiles_per_span;
@@ -194,7 +194,9 @@ __device__ __forceinline__ void element_op(float v, const typename ModeTraits<MO
     }
 }
 
-template <int MODE, bool LDS, int BLOCK>
+// PSCHK: some workgroup touches more ranks than the LDS per-segment window holds, so fetches
+// must check the window and fall back to global memory (decided on the host from the layout).
+template <int MODE, bool LDS, int BLOCK, bool PSCHK>
 __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     using TR = ModeTraits<MODE>;
     using G = typename TR::G;
@@ -202,10 +204,10 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     G* __restrict__ slice = reinterpret_cast<G*>(lds_raw);
     const uint32_t lane = threadIdx.x & 63;
-    // wave-uniform values are forced into SGPRs so that flag words / span metadata become scalar loads
     const uint32_t span = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
     const G* __restrict__ gather = static_cast<const G*>(a.gather);
     const P* __restrict__ perseg = static_cast<const P*>(a.perseg);
+    const uint32_t span_words = a.tiles_per_span * (kTileElems / 32);
     if constexpr (LDS) {
         // stage this workgroup's panel slice; slot panel_rows is the zero entry padding points at
         const uint32_t panel = a.wg_panel[blockIdx.x];
@@ -217,65 +219,72 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     // The workgroup touches a contiguous window of ranks; stage their per-segment operands next to
     // the slice so that segmented tiles read LDS instead of chasing seg_of_rank -> perseg through L2.
     P* __restrict__ ps_lds = reinterpret_cast<P*>(lds_raw + (((size_t) a.panel_rows + 1) * sizeof(G) + 15) / 16 * 16);
-    int32_t win_base = 0;
+    uint32_t win_base = 0;
     if constexpr (LDS && TR::kPerSeg) {
-        const uint32_t first = blockIdx.x * (BLOCK / 64), next = first + BLOCK / 64;
-        const int32_t rb0 = (int32_t) a.span_rank_base[first];
+        const uint32_t first = blockIdx.x * (BLOCK / 64);
+        const uint32_t rb0 = a.hpre[(size_t) first * span_words];
         win_base = rb0 > 0 ? rb0 - 1 : 0;
-        const uint32_t win_end = next < a.nspans ? a.span_rank_base[next] : a.nne;
-        uint32_t cnt = win_end - (uint32_t) win_base;
+        const uint32_t win_end = a.hpre[(size_t) (first + BLOCK / 64) * span_words];  // heads before the next chunk
+        uint32_t cnt = win_end - win_base;
         if (cnt > kPerSegLdsCap) cnt = kPerSegLdsCap;
         for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) ps_lds[j] = perseg[a.seg_of_rank[win_base + j]];
     }
     if constexpr (LDS) __syncthreads();
     if (span >= a.nspans) return;
-    auto fetch_ps = [&](int32_t r) -> P {
+    auto fetch_ps = [&](uint32_t r) -> P {  // r: rank, always valid where this is called
         if constexpr (LDS) {
-            const uint32_t rl = (uint32_t) (r - win_base);
-            if (rl < kPerSegLdsCap) return ps_lds[rl];
+            const uint32_t rl = r - win_base;
+            if constexpr (!PSCHK) return ps_lds[rl];
+            else if (rl < kPerSegLdsCap) return ps_lds[rl];
         }
         return perseg[a.seg_of_rank[r]];
     };
     const uint64_t start = (uint64_t) span * a.tiles_per_span * kTileElems;
-    const int32_t rank_base = (int32_t) a.span_rank_base[span];
-    int32_t cur = rank_base - 1;  // rank of the segment that is open at the current position
-    P pcur{};
-    if constexpr (TR::kPerSeg) {
-        if (cur >= 0) pcur = fetch_ps(cur);
-    }
-    float og = 0.f, oh = 0.f;  // per-lane sums of the open segment since its last head
-    bool open_spread = false;  // wave-uniform: og/oh hold per-lane partials (else only lane 0 is non-zero)
 
     // panel-local indices are 16-bit: 2 B/nnz instead of 4 (10 B/nnz per fused pass instead of 12)
     using IdxVec = typename std::conditional<LDS, u16x4, u32x4>::type;
     using IdxElem = typename std::conditional<LDS, uint16_t, uint32_t>::type;
     const IdxVec* __restrict__ idx4 = reinterpret_cast<const IdxVec*>(static_cast<const IdxElem*>(a.idx) + start) + lane;
     f32x4* __restrict__ val4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
+    // per-lane view of the head metadata: 8 lanes share one 32-element word
+    const uint32_t* __restrict__ flw = a.flags32 + (size_t) span * span_words + (lane >> 3);
+    const uint32_t* __restrict__ hpw = a.hpre + (size_t) span * span_words + (lane >> 3);
+    const uint32_t sh = (lane & 7) * 4;
     uint32_t ntiles = a.tiles_per_span;
     if constexpr (!LDS) {  // plain layout: tiles that start at or beyond nnz hold only padding
         const uint64_t left = a.nnz > start ? a.nnz - start : 0;
         const uint32_t live = (uint32_t) ((left + kTileElems - 1) / kTileElems);
         if (live < ntiles) ntiles = live;
     }
-    IdxVec id_n = {0, 0, 0, 0};
-    f32x4 v_n = {0.f, 0.f, 0.f, 0.f};
-    const uint64_t* __restrict__ fw = a.flags + (start >> 6);  // 4 words per tile, wave-uniform (scalar loads)
-    uint64_t f0_n = 0, f1_n = 0, f2_n = 0, f3_n = 0;
-    if (ntiles) {
-        id_n = __builtin_nontemporal_load(idx4);
-        v_n = __builtin_nontemporal_load(val4);
-        f0_n = fw[0]; f1_n = fw[1]; f2_n = fw[2]; f3_n = fw[3];
+    if (ntiles == 0) {  // nothing stored here (plain layout, nnz == 0): still own the carry slot
+        if (TR::kDot && lane == 0) { a.carry_g[span] = 0.f; a.carry_h[span] = 0.f; }
+        return;
     }
+    IdxVec id_n = __builtin_nontemporal_load(idx4);
+    f32x4 v_n = __builtin_nontemporal_load(val4);
+    uint32_t fl_n = flw[0], hp_n = hpw[0];
+    const uint32_t rank_base = __builtin_amdgcn_readfirstlane(hp_n);  // heads before this span
+    uint32_t cur1 = rank_base;  // (rank of the segment open at the current position) + 1, wave-uniform
+    P pcur{};
+    if constexpr (TR::kPerSeg) {
+        if (cur1 > 0) pcur = fetch_ps(cur1 - 1);
+    }
+    float og = 0.f, oh = 0.f;  // per-lane sums of the open segment since its last head
+    bool open_spread = false;  // wave-uniform: og/oh hold per-lane partials (else only lane 0 is non-zero)
+
     for (uint32_t tile = 0; tile < ntiles; ++tile) {
         const IdxVec id = id_n;
         const f32x4 v = v_n;
-        const uint64_t w0 = f0_n, w1 = f1_n, w2 = f2_n, w3 = f3_n;
-        if (tile + 1 < ntiles) {  // prefetch the next tile's streams and head flags (one tile ahead)
+        const uint32_t fl = fl_n, hp = hp_n;
+        // next tile's streams and head metadata, one tile ahead (the metadata arrays carry 8 spare
+        // words, so reading one tile past the last span is in bounds and gives heads_total)
+        if (tile + 1 < ntiles) {
             id_n = __builtin_nontemporal_load(idx4 + (tile + 1) * 64);
             v_n = __builtin_nontemporal_load(val4 + (tile + 1) * 64);
-            const uint64_t* fn = fw + (tile + 1) * 4;
-            f0_n = fn[0]; f1_n = fn[1]; f2_n = fn[2]; f3_n = fn[3];
         }
+        fl_n = flw[(tile + 1) * 8];
+        hp_n = hpw[(tile + 1) * 8];
+        const uint32_t cur1_next = __builtin_amdgcn_readfirstlane(hp_n);  // heads before the next tile
         const uint64_t base = start + (uint64_t) tile * kTileElems;
         // plain layout only: the tile that straddles nnz needs its padding masked; with LDS panels
         // padding gathers the zero slot and contributes exact zeros
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         for (int e = 0; e < 4; ++e) ga[e] = LDS ? slice[ids[e]] : gather[ids[e]];
         float vo[4], gc[4], hc[4];
 
-        if ((w0 | w1 | w2 | w3) == 0 || (a.dbg & 1)) {
+        if (cur1_next == cur1 || (a.dbg & 1)) {
             // ---- no segment starts in this tile: everything belongs to the open segment ----
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -300,21 +309,17 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
             open_spread = true;
         } else {
             // ---- segmented tile ----
-            const uint32_t wsel = lane >> 4;
-            const uint64_t myw = wsel == 0 ? w0 : wsel == 1 ? w1 : wsel == 2 ? w2 : w3;
-            const uint32_t c0 = __popcll(w0), c1 = c0 + __popcll(w1), c2 = c1 + __popcll(w2);
-            const uint32_t ctot = c2 + __popcll(w3);
-            const uint32_t below = wsel == 0 ? 0u : wsel == 1 ? c0 : wsel == 2 ? c1 : c2;
-            const uint32_t sh = (lane & 15) * 4;
-            const uint32_t nib = (uint32_t) (myw >> sh) & 0xFu;
-            // heads in the tile before this lane's first element
-            const uint32_t before = below + __popcll(myw & ((uint64_t(1) << sh) - 1));
+            const uint32_t nib = (fl >> sh) & 0xFu;
+            // (rank open at this lane's first element) + 1 = heads before it, globally
+            const uint32_t r1 = hp + (uint32_t) __popc(fl & ((1u << sh) - 1u));
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 P ps{};
                 if constexpr (TR::kPerSeg) {
-                    const int32_t r = cur + (int32_t) before + (int32_t) __popc(nib & ((2u << e) - 1u));
-                    ps = (a.dbg & 2) ? pcur : fetch_ps(r);
+                    // element e's rank + 1 = r1 + heads among elements 0..e of this lane (>= 1 always:
+                    // the very first stored element is a head)
+                    const uint32_t re1 = r1 + (uint32_t) __popc(nib & ((2u << e) - 1u));
+                    ps = (a.dbg & 2) ? pcur : fetch_ps(re1 - 1);
                 }
                 element_op<MODE>(vs[e], ga[e], ps, a.add, vo[e], gc[e], hc[e]);
                 if (partial && e0 + e >= a.nnz) { gc[e] = 0.f; hc[e] = 0.f; }
@@ -334,17 +339,17 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                 // last head; runs between two heads of the same lane are complete segments.
                 float ag = 0.f, ah = 0.f, fg = 0.f, fh = 0.f;
                 bool seen = false;
-                int32_t r_close = cur + (int32_t) before;  // rank closed by the lane's next head
+                uint32_t close1 = r1;  // (rank closed by the lane's next head) + 1
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if ((nib >> e) & 1u) {
                         if (!seen) {
                             fg = ag; fh = ah; seen = true;
                         } else {  // head..head inside one lane: started in this span by construction
-                            a.gpart[r_close] = ag;
-                            a.hpart[r_close] = ah;
+                            a.gpart[close1 - 1] = ag;
+                            a.hpart[close1 - 1] = ah;
                         }
-                        ++r_close;
+                        ++close1;
                         ag = 0.f; ah = 0.f;
                     }
                     ag += gc[e];
@@ -359,12 +364,11 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                 seg_scan2(xg, xh, lane, dist);
                 float eg = dpp_mov<kDppWaveShr1>(xg), eh = dpp_mov<kDppWaveShr1>(xh);  // exclusive: lane l-1
                 if ((M & ((uint64_t(1) << lane) - 1)) == 0) { eg += cin_g; eh += cin_h; }
-                if (seen) {  // this lane's first head closes the segment of rank cur+before
-                    const int32_t rc = cur + (int32_t) before;
+                if (seen) {  // this lane's first head closes the segment of rank r1 - 1
                     const float tg = eg + fg, th = eh + fh;
-                    if (rc >= rank_base) {
-                        a.gpart[rc] = tg;
-                        a.hpart[rc] = th;
+                    if (r1 > rank_base) {  // it started inside this span: we own its slot
+                        a.gpart[r1 - 1] = tg;
+                        a.hpart[r1 - 1] = th;
                     } else {  // it started in an earlier span: this is the span's head carry
                         a.carry_g[span] = tg;
                         a.carry_h[span] = th;
@@ -376,8 +380,8 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                 og = lane == 0 ? ng : 0.f;
                 oh = lane == 0 ? nh : 0.f;
             }
-            cur += (int32_t) ctot;
-            if constexpr (TR::kPerSeg) pcur = fetch_ps(cur);
+            cur1 = cur1_next;
+            if constexpr (TR::kPerSeg) pcur = fetch_ps(cur1 - 1);
         }
         if constexpr (TR::kWrite) {
             if (!partial) {
@@ -393,9 +397,9 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     if constexpr (TR::kDot) {
         const float tg = open_spread ? wave_sum(og) : og, th = open_spread ? wave_sum(oh) : oh;
         if (lane == 0) {
-            if (cur >= rank_base) {  // the open segment's head lies in this span: we own its slot
-                a.gpart[cur] = tg;
-                a.hpart[cur] = th;
+            if (cur1 > rank_base) {  // the open segment's head lies in this span: we own its slot
+                a.gpart[cur1 - 1] = tg;
+                a.hpart[cur1 - 1] = th;
             } else {  // the whole span is interior to one segment
                 a.carry_g[span] = tg;
                 a.carry_h[span] = th;
@@ -578,33 +582,40 @@ uint32_t seg_grid(uint32_t nseg) {
 
 #define MFX_LAUNCH_CHECK() MFX_HIP(hipGetLastError())
 
-template <int MODE, bool LDS, int BLOCK>
+template <int MODE, bool LDS, int BLOCK, bool PSCHK>
 int launch_flat_t(const FlatArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
     if (lds_bytes > 48 * 1024) {
         static size_t attr_bytes = 0;  // per instantiation
         if (lds_bytes > attr_bytes) {
-            MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat<MODE, LDS, BLOCK>),
+            MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat<MODE, LDS, BLOCK, PSCHK>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
             attr_bytes = lds_bytes;
         }
     }
-    hipLaunchKernelGGL((k_flat<MODE, LDS, BLOCK>), dim3(grid), dim3(BLOCK), lds_bytes, st, a);
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL((k_flat<MODE, LDS, BLOCK, PSCHK>), dim3(grid), dim3(BLOCK), lds_bytes, st, a);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
+}
+
+template <int MODE, int BLOCK>
+int launch_flat_lds(const SegStreamDev& s, const FlatArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
+    if (ModeTraits<MODE>::kPerSeg && s.max_wg_ranks > kPerSegLdsCap)
+        return launch_flat_t<MODE, true, BLOCK, true>(a, grid, lds_bytes, st);
+    return launch_flat_t<MODE, true, BLOCK, false>(a, grid, lds_bytes, st);
 }
 
 template <int MODE>
 int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
     using G = typename ModeTraits<MODE>::G;
     if (s.panel_rows == 0)
-        return launch_flat_t<MODE, false, kBlock>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), 0, st);
+        return launch_flat_t<MODE, false, kBlock, false>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), 0, st);
     size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(G) + 15) / 16 * 16;
     if (ModeTraits<MODE>::kPerSeg) lds_bytes += (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
     const uint32_t grid = s.nspans / s.spans_per_wg;
     switch (s.spans_per_wg) {
-        case 4: return launch_flat_t<MODE, true, 256>(a, grid, lds_bytes, st);
-        case 8: return launch_flat_t<MODE, true, 512>(a, grid, lds_bytes, st);
-        case 16: return launch_flat_t<MODE, true, 1024>(a, grid, lds_bytes, st);
+        case 4: return launch_flat_lds<MODE, 256>(s, a, grid, lds_bytes, st);
+        case 8: return launch_flat_lds<MODE, 512>(s, a, grid, lds_bytes, st);
+        case 16: return launch_flat_lds<MODE, 1024>(s, a, grid, lds_bytes, st);
         default: return fail(MFX_ERR_INVALID, "panel layout: spans_per_wg must be 4, 8 or 16 (got %u)", s.spans_per_wg);
     }
 }
@@ -613,8 +624,8 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
                 hipStream_t st) {
     FlatArgs a;
     a.idx = s.panel_rows ? static_cast<const void*>(s.idx16) : static_cast<const void*>(s.idx);
-    a.val = s.val; a.flags = s.flags; a.seg_of_rank = s.seg_of_rank;
-    a.span_rank_base = s.span_rank_base; a.wg_panel = s.wg_panel; a.nspans = s.nspans;
+    a.val = s.val; a.flags32 = s.flags32; a.hpre = s.hpre; a.seg_of_rank = s.seg_of_rank;
+    a.wg_panel = s.wg_panel; a.nspans = s.nspans;
     a.tiles_per_span = s.tiles_per_span; a.panel_rows = s.panel_rows; a.gather_len = s.gather_len; a.nne = s.nne;
     a.nnz = s.nnz; a.gather = gather; a.perseg = perseg; a.gpart = s.gpart; a.hpart = s.hpart;
     a.carry_g = s.carry_g; a.carry_h = s.carry_h; a.add = add;
@@ -632,7 +643,7 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
 int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, float* h_dense, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
     MFX_REQUIRE(s.panel_rows == 0, "wave-per-segment kernels need the plain layout");
-    hipLaunchKernelGGL(k_sweep_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_sweep_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
                        vec, g_dense, h_dense);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
@@ -641,7 +652,7 @@ int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, f
 int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float* per_seg, int add, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
     MFX_REQUIRE(s.panel_rows == 0, "wave-per-segment kernels need the plain layout");
-    hipLaunchKernelGGL(k_resid_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_resid_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
                        gathered, per_seg, add);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
@@ -661,6 +672,7 @@ int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st) {
     const GatherPartsArgs a = parts_of(s);
     const int pl = panel_lanes(s);
     const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
+    MFX_CLEAR_STALE_ERROR();
     if (pl == 16) hipLaunchKernelGGL(k_combine_dense<16>, grid, block, 0, st, a, gh);
     else if (pl == 4) hipLaunchKernelGGL(k_combine_dense<4>, grid, block, 0, st, a, gh);
     else hipLaunchKernelGGL(k_combine_dense<1>, grid, block, 0, st, a, gh);
@@ -675,6 +687,7 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
     a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
     const int pl = f.gh_dense ? 1 : panel_lanes(s);
     const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
+    MFX_CLEAR_STALE_ERROR();
     if (pl == 16) hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, st, a);
     else if (pl == 4) hipLaunchKernelGGL(k_finalize<4>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_finalize<1>, grid, block, 0, st, a);
@@ -684,7 +697,7 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
 
 int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st) {
     if (s.padded_nnz == 0) return MFX_OK;
-    hipLaunchKernelGGL(k_unpermute, dim3((uint32_t) ((s.padded_nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_unpermute, dim3((uint32_t) ((s.padded_nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        s.padded_nnz, s.perm, s.val, out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
@@ -692,7 +705,7 @@ int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st) {
 
 int launch_pack2(uint32_t n, const float* x, const float* y, float2* pack, hipStream_t st) {
     if (n == 0) return MFX_OK;
-    hipLaunchKernelGGL(k_pack2, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, x, y, pack);
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_pack2, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, x, y, pack);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }
@@ -700,10 +713,10 @@ int launch_pack2(uint32_t n, const float* x, const float* y, float2* pack, hipSt
 int launch_test_sqerr(int64_t nnz_test, const uint32_t* row, const uint32_t* col, const float* val,
                       const float* W, const float* H, int64_t rows, int64_t cols, int64_t k, int ifALS,
                       double* block_partials, uint32_t nblocks, double* sum_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_test_sqerr, dim3(nblocks), dim3(kBlock), 0, st, nnz_test, row, col, val, W, H, rows,
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_test_sqerr, dim3(nblocks), dim3(kBlock), 0, st, nnz_test, row, col, val, W, H, rows,
                        cols, k, ifALS, block_partials);
     MFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, nblocks, block_partials, sum_out);
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, nblocks, block_partials, sum_out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }

@@ -31,10 +31,11 @@ struct SegStreamDev {
     const uint32_t* idx = nullptr;             // [padded nnz] gathered index (plain layout)
     const uint16_t* idx16 = nullptr;           // [padded nnz] panel-local gathered index (LDS panels)
     float* val = nullptr;                      // [padded nnz] residual copy, updated in place
-    const uint64_t* flags = nullptr;           // [padded nnz / 64]
+    const uint32_t* flags32 = nullptr;         // [padded nnz / 32 + 8] head bits
+    const uint32_t* hpre = nullptr;            // [padded nnz / 32 + 8] heads before each word
+    uint32_t max_wg_ranks = 0;                 // most ranks any workgroup chunk touches
     const int32_t* rank_of_seg = nullptr;      // [npanels*nseg]
     const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id
-    const uint32_t* span_rank_base = nullptr;  // [nspans]
     const uint32_t* wg_panel = nullptr;        // [nspans/spans_per_wg]
     const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding
     // reduction scratch written by the flat kernels

@@ -77,14 +77,14 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_TRY(perm_.upload(L.perm.data(), L.padded_nnz, MFX_HOST, st));
     MFX_TRY(val_.alloc(L.padded_nnz));
     MFX_TRY(val_.upload(val_st.data(), L.padded_nnz, MFX_HOST, st));
-    MFX_TRY(flags_.alloc(L.flags.size()));
-    MFX_TRY(flags_.upload(L.flags.data(), L.flags.size(), MFX_HOST, st));
+    MFX_TRY(flags32_.alloc(L.flags32.size()));
+    MFX_TRY(flags32_.upload(L.flags32.data(), L.flags32.size(), MFX_HOST, st));
+    MFX_TRY(hpre_.alloc(L.hpre.size()));
+    MFX_TRY(hpre_.upload(L.hpre.data(), L.hpre.size(), MFX_HOST, st));
     MFX_TRY(rank_of_seg_.alloc(nv));
     MFX_TRY(rank_of_seg_.upload(L.rank_of_seg.data(), nv, MFX_HOST, st));
     MFX_TRY(seg_of_rank_.alloc(L.nne ? L.nne : 1));
     MFX_TRY(seg_of_rank_.upload(L.seg_of_rank.data(), L.nne, MFX_HOST, st));
-    MFX_TRY(span_rank_base_.alloc(L.nspans));
-    MFX_TRY(span_rank_base_.upload(L.span_rank_base.data(), L.nspans, MFX_HOST, st));
     MFX_TRY(wg_panel_.alloc(L.wg_panel.empty() ? 1 : L.wg_panel.size()));
     MFX_TRY(wg_panel_.upload(L.wg_panel.data(), L.wg_panel.size(), MFX_HOST, st));
     MFX_TRY(gpart_.alloc_zero(L.nne ? L.nne : 1, st));
@@ -99,13 +99,13 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     view.spans_per_wg = L.spans_per_wg; view.gather_len = G;
     view.ptr = ptr_.get(); view.ptr_v = ptr_v_.get(); view.seg_cnt = seg_cnt_.get(); view.idx = idx_.get();
     view.idx16 = idx16_.get();
-    view.val = val_.get(); view.flags = flags_.get(); view.rank_of_seg = rank_of_seg_.get();
-    view.seg_of_rank = seg_of_rank_.get(); view.span_rank_base = span_rank_base_.get();
+    view.val = val_.get(); view.flags32 = flags32_.get(); view.hpre = hpre_.get(); view.rank_of_seg = rank_of_seg_.get();
+    view.seg_of_rank = seg_of_rank_.get(); view.max_wg_ranks = L.max_wg_ranks;
     view.wg_panel = wg_panel_.get(); view.perm = perm_.get(); view.gpart = gpart_.get(); view.hpart = hpart_.get();
     view.carry_g = carry_g_.get(); view.carry_h = carry_h_.get();
     // the big host-side vectors are no longer needed
     for (auto* v : {&L.idx_local, &L.perm}) { v->clear(); v->shrink_to_fit(); }
-    L.flags.clear(); L.flags.shrink_to_fit();
+    for (auto* v : {&L.flags32, &L.hpre}) { v->clear(); v->shrink_to_fit(); }
     return MFX_OK;
 }
 

@@ -25,9 +25,8 @@ public:
 
 private:
     FlatLayoutHost layout_;
-    DevBuf<uint32_t> ptr_, ptr_v_, seg_cnt_, idx_, seg_of_rank_, span_rank_base_, wg_panel_, perm_;
+    DevBuf<uint32_t> ptr_, ptr_v_, seg_cnt_, idx_, seg_of_rank_, flags32_, hpre_, wg_panel_, perm_;
     DevBuf<float> val_, gpart_, hpart_, carry_g_, carry_h_;
-    DevBuf<uint64_t> flags_;
     DevBuf<int32_t> rank_of_seg_;
     DevBuf<uint16_t> idx16_;
 };

@@ -98,29 +98,33 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
         }
     });
 
-    // 4. head flags, ranks, span bases over the virtual segments
-    L.flags.assign(L.padded_nnz / 64, 0);
+    // 4. head flags, ranks and per-word head prefix counts over the virtual segments
+    const size_t nwords = L.padded_nnz / 32;
+    L.flags32.assign(nwords + 8, 0);
     L.rank_of_seg.assign(nv, -1);
     L.seg_of_rank.clear();
     L.seg_of_rank.reserve(std::min<size_t>(nv, (size_t) nnz + P));
-    std::vector<uint32_t> head_pos;
-    head_pos.reserve(L.seg_of_rank.capacity());
     for (size_t v = 0; v < nv; ++v) {
         if (L.ptr_v[v + 1] > L.ptr_v[v]) {
             L.rank_of_seg[v] = (int32_t) L.seg_of_rank.size();
             L.seg_of_rank.push_back((uint32_t) (v % nseg));
             const uint64_t head = L.ptr_v[v];
-            head_pos.push_back((uint32_t) head);
-            L.flags[head >> 6] |= uint64_t(1) << (head & 63);
+            L.flags32[head >> 5] |= 1u << (head & 31);
         }
     }
     L.nne = (uint32_t) L.seg_of_rank.size();
-    L.span_rank_base.assign(L.nspans, 0);
-    uint32_t r = 0;
-    for (uint32_t s = 0; s < L.nspans; ++s) {
-        const uint64_t start = (uint64_t) s * span;
-        while (r < L.nne && head_pos[r] < start) ++r;
-        L.span_rank_base[s] = r;  // heads strictly before the span's first element
+    L.hpre.assign(nwords + 8, 0);
+    uint32_t run = 0;
+    for (size_t w = 0; w < nwords + 8; ++w) {
+        L.hpre[w] = run;
+        run += (uint32_t) __builtin_popcount(L.flags32[w]);
+    }
+    {   // most ranks one workgroup chunk touches: sizes the LDS per-segment window (or its fallback)
+        const uint64_t chunk_words = chunk / 32;
+        for (uint64_t w0 = 0; w0 < nwords; w0 += chunk_words) {
+            const uint32_t lo = L.hpre[w0] > 0 ? L.hpre[w0] - 1 : 0, hi = L.hpre[std::min<uint64_t>(w0 + chunk_words, nwords)];
+            L.max_wg_ranks = std::max(L.max_wg_ranks, hi - lo);
+        }
     }
     // 5. workgroup -> panel
     if (PR) {

@@ -18,9 +18,11 @@
 //   span            L = 256 * tiles_per_span consecutive stored non-zeros, owned by one wavefront
 //                   (64 lanes x 4 consecutive non-zeros per tile, 16-byte loads); a workgroup
 //                   chunk is spans_per_wg consecutive spans of ONE panel.
-//   head flag       1 bit per stored non-zero: "first entry of its virtual segment"
-//   rank            index of a virtual segment among the NON-EMPTY ones; element -> rank is a
-//                   popcount of head flags.  span_rank_base = heads before the span.
+//   head flag       1 bit per stored non-zero: "first entry of its virtual segment", kept as one
+//                   32-bit word per 32 stored non-zeros (flags32)
+//   rank            index of a virtual segment among the NON-EMPTY ones.  hpre[w] = number of heads
+//                   before word w, so element -> rank is hpre[w] + popcount(flags32[w] & below) - 1:
+//                   two small per-lane loads per tile (0.25 B/nnz) instead of a per-nnz segment id.
 //
 // Reduction contract (ccd_kernels.hip): the span that contains a virtual segment's head stores that
 // segment's partial sum to part[rank] (exactly one writer, plain store); a span whose first element
@@ -47,12 +49,13 @@ struct FlatLayoutHost {
     uint32_t tiles_per_span = 0;
     uint64_t nnz = 0;             // real non-zeros
     uint64_t padded_nnz = 0;      // stored elements (nspans * span length)
+    uint32_t max_wg_ranks = 0;    // most ranks any workgroup chunk touches (incl. the one open at its start)
     std::vector<uint32_t> ptr_v;           // [npanels*nseg + 1]
     std::vector<uint32_t> seg_cnt;         // [nseg] real entries per segment
-    std::vector<uint64_t> flags;           // [padded_nnz / 64]
+    std::vector<uint32_t> flags32;         // [padded_nnz / 32 + 8] head bits (tail words zero)
+    std::vector<uint32_t> hpre;            // [padded_nnz / 32 + 8] heads before each word (tail = nne)
     std::vector<int32_t> rank_of_seg;      // [npanels*nseg], -1 for an empty virtual segment
     std::vector<uint32_t> seg_of_rank;     // [nne] REAL segment id of each rank
-    std::vector<uint32_t> span_rank_base;  // [nspans]
     std::vector<uint32_t> wg_panel;        // [nspans / spans_per_wg] (panel layout only)
     std::vector<uint32_t> idx_local;       // [padded_nnz] panel-local gathered index (pad: zero slot)
     std::vector<uint32_t> perm;            // [padded_nnz] input position of each stored element, ~0u for pad

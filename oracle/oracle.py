@@ -27,6 +27,7 @@ def build() -> None:
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # no spinning barriers on a shared host
         path = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
@@ -46,8 +47,29 @@ def _chk(a, dt):
     return a
 
 
+def _usable_cores() -> int:
+    """Cores this process can really run on: affinity mask capped by the cgroup CPU quota.  A GPU
+    box shows every logical CPU of the host (128-256) but grants one GPU's share of them;
+    starting that many OpenMP threads with spinning barriers makes the oracle crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def max_threads() -> int:
-    return int(lib().orc_max_threads())
+    """Threads to run the oracle with: min(OpenMP's idea, usable cores, 32)."""
+    return max(1, min(int(lib().orc_max_threads()), _usable_cores(), 32))
 
 
 def initial_col(k: int, n: int) -> np.ndarray:

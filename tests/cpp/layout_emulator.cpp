@@ -45,11 +45,14 @@ static int check(uint32_t nseg, uint32_t G, const std::vector<uint32_t>& lens, c
     // replay the kernel's span walk
     std::vector<long long> part(L.nne ? L.nne : 1, -777), carry(L.nspans, -777);
     for (uint32_t s = 0; s < L.nspans; ++s) {
-        const int rank_base = (int) L.span_rank_base[s];
+        const int rank_base = (int) L.hpre[(uint64_t) s * span / 32];
         int cur = rank_base - 1;
         long long acc = 0;
         for (uint64_t e = (uint64_t) s * span; e < (uint64_t) (s + 1) * span; ++e) {
-            if ((L.flags[e >> 6] >> (e & 63)) & 1) {
+            // rank of the segment open BEFORE e, from the per-word prefix: must agree with the walk
+            const int open_rank = (int) (L.hpre[e >> 5] + __builtin_popcount(L.flags32[e >> 5] & ((1u << (e & 31)) - 1))) - 1;
+            if (open_rank != cur) { printf("hpre mismatch at %llu\n", (unsigned long long) e); return 1; }
+            if ((L.flags32[e >> 5] >> (e & 31)) & 1) {
                 if (cur >= rank_base) part[cur] = acc; else carry[s] = acc;
                 ++cur;
                 acc = 0;

@@ -73,6 +73,89 @@ __global__ __launch_bounds__(BLOCK) void k_pass(const uint32_t* __restrict__ idx
     if (lane == 0) { out[2 * wave] = g; out[2 * wave + 1] = h; }
 }
 
+
+using u16x8 = __attribute__((ext_vector_type(8))) uint16_t;
+using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
+
+// EPL = elements per lane: 4 (u16x4 idx + one f32x4) or 8 (u16x8 idx + two f32x4 at 32-B lane stride)
+template <int EPL, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_pass16(const uint16_t* __restrict__ idx, float* __restrict__ val,
+                                                  const float2* __restrict__ vec, uint32_t vlen, uint32_t tiles_per_wave,
+                                                  uint64_t nnz, float* __restrict__ out) {
+    extern __shared__ float2 lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    for (uint32_t i = threadIdx.x; i < vlen; i += BLOCK) lds[i] = vec[i];
+    __syncthreads();
+    constexpr int TILE = 64 * EPL;
+    const uint64_t start = (uint64_t) wave * tiles_per_wave * TILE;
+    if (start >= nnz) return;
+    float g = 0.f, h = 0.f;
+    if constexpr (EPL == 4) {
+        const u16x4* i4 = reinterpret_cast<const u16x4*>(idx + start) + lane;
+        f32x4* v4 = reinterpret_cast<f32x4*>(val + start) + lane;
+        u16x4 idn = __builtin_nontemporal_load(i4);
+        f32x4 vn = __builtin_nontemporal_load(v4);
+        for (uint32_t t = 0; t < tiles_per_wave; ++t) {
+            const u16x4 id = idn; const f32x4 v = vn;
+            if (t + 1 < tiles_per_wave) { idn = __builtin_nontemporal_load(i4 + (t + 1) * 64); vn = __builtin_nontemporal_load(v4 + (t + 1) * 64); }
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 a = lds[id[e]];
+                const float nv = (v[e] - a.x * 0.25f) + a.y * 0.125f;
+                o[e] = nv; g += a.y * nv; h += a.y * a.y;
+            }
+            __builtin_nontemporal_store(o, v4 + t * 64);
+        }
+    } else {
+        const u16x8* i8 = reinterpret_cast<const u16x8*>(idx + start) + lane;
+        f32x4* v4 = reinterpret_cast<f32x4*>(val + start) + 2 * lane;
+        u16x8 idn = __builtin_nontemporal_load(i8);
+        f32x4 vn0 = __builtin_nontemporal_load(v4), vn1 = __builtin_nontemporal_load(v4 + 1);
+        for (uint32_t t = 0; t < tiles_per_wave; ++t) {
+            const u16x8 id = idn; const f32x4 v0 = vn0, v1 = vn1;
+            if (t + 1 < tiles_per_wave) {
+                idn = __builtin_nontemporal_load(i8 + (t + 1) * 64);
+                vn0 = __builtin_nontemporal_load(v4 + (t + 1) * 128); vn1 = __builtin_nontemporal_load(v4 + (t + 1) * 128 + 1);
+            }
+            f32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 a = lds[id[e]];
+                const float vv = e < 4 ? v0[e & 3] : v1[e & 3];
+                const float nv = (vv - a.x * 0.25f) + a.y * 0.125f;
+                if (e < 4) o0[e & 3] = nv; else o1[e & 3] = nv;
+                g += a.y * nv; h += a.y * a.y;
+            }
+            __builtin_nontemporal_store(o0, v4 + t * 128);
+            __builtin_nontemporal_store(o1, v4 + t * 128 + 1);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); h += __shfl_xor(h, o, 64); }
+    if (lane == 0) { out[2 * wave] = g; out[2 * wave + 1] = h; }
+}
+
+template <int EPL, int BLOCK>
+void run16(const char* name, const uint16_t* idx, float* val, const float2* vec, uint32_t vlen, uint32_t tiles, uint64_t nnz, float* out) {
+    const uint64_t per_wave = (uint64_t) tiles * 64 * EPL;
+    const uint64_t waves = (nnz + per_wave - 1) / per_wave;
+    const uint32_t grid = (uint32_t) ((waves + BLOCK / 64 - 1) / (BLOCK / 64));
+    const size_t lds = (size_t) vlen * sizeof(float2);
+    if (lds > 48 * 1024) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pass16<EPL, BLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL((k_pass16<EPL, BLOCK>), dim3(grid), dim3(BLOCK), lds, 0, idx, val, vec, vlen, tiles, nnz, out);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    CK(hipGetLastError());
+    printf("%-44s vlen=%8u tiles=%3u block=%4d  %8.1f us  %7.1f GB/s (10 B/nnz)\n", name, vlen, tiles, BLOCK, best * 1e3, 10.0 * nnz / (best * 1e-3) / 1e9);
+}
+
 template <int GATHER, bool NT, int DEPTH, int BLOCK>
 void run(const char* name, const uint32_t* idx, float* val, const float2* vec, uint32_t vlen, uint32_t tiles,
          uint64_t nnz, float* out) {
@@ -106,6 +189,21 @@ int main(int argc, char** argv) {
     std::vector<float2> hv(vmax, make_float2(0.5f, 0.25f));
     CK(hipMemcpy(vec, hv.data(), vmax * 8, hipMemcpyHostToDevice));
     CK(hipMemset(val, 0, nnz * 4));
+
+    {   // 16-bit indices: 4 vs 8 elements per lane
+        const uint32_t vlen = 7168;
+        std::vector<uint16_t> h16(nnz);
+        uint64_t s2 = 424242;
+        for (uint64_t i = 0; i < nnz; ++i) { s2 ^= s2 << 13; s2 ^= s2 >> 7; s2 ^= s2 << 17; h16[i] = (uint16_t) (s2 % vlen); }
+        uint16_t* d16; CK(hipMalloc(&d16, nnz * 2)); CK(hipMemcpy(d16, h16.data(), nnz * 2, hipMemcpyHostToDevice));
+        printf("---- u16 indices, vlen %u ----\n", vlen);
+        run16<4, 1024>("u16 LDS gather, 4 el/lane, 1024thr, t8", d16, val, vec, vlen, 8, nnz, out);
+        run16<8, 1024>("u16 LDS gather, 8 el/lane, 1024thr, t4", d16, val, vec, vlen, 4, nnz, out);
+        run16<8, 1024>("u16 LDS gather, 8 el/lane, 1024thr, t8", d16, val, vec, vlen, 8, nnz, out);
+        run16<4, 512>("u16 LDS gather, 4 el/lane, 512thr, t8", d16, val, vec, vlen, 8, nnz, out);
+        run16<8, 512>("u16 LDS gather, 8 el/lane, 512thr, t4", d16, val, vec, vlen, 4, nnz, out);
+        return 0;
+    }
     std::vector<uint32_t> hi(nnz);
     for (uint32_t vlen : {480189u, 17770u, 8192u}) {
         // sorted-ish within runs like a real column: random walk with random restarts
