@@ -52,6 +52,31 @@ def host_cores() -> int:
     return max(1, n)
 
 
+def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
+    """Secondary measurement (BASELINE configs[3]): ALS iteration time on the same synthetic matrix."""
+    import numpy as np
+    host = synth_torch.to_rating_data(d)
+    p = mfx.parameter()
+    p.k, p.lambda_ = a.k, a.lam
+    s = mfx.AlsSolver(host, mfx.test_data_of(host), p)
+    s.set_factors(mfx.initial_col(host.cols, a.k))
+    s.iterate(a.warmup, with_rmse=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rep = s.iterate(a.steps, with_rmse=True)
+    el = time.perf_counter() - t0
+    kt = s.kernel_times()
+    Z, k = host.nnz, a.k
+    flops = 2.0 * (Z * k * (k + 1) + 2.0 * Z * k)  # both half-sweeps: symmetric Gramian + rhs
+    print(json.dumps({"metric": "ALS iteration time at k=%d" % k, "value": round(1e3 * el / a.steps, 3), "unit": "ms",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": False, "dtype": "f32",
+                      "data": "synthetic", "config": {"workload": f"{host.rows}x{host.cols} nnz={Z} k={k}"},
+                      "gramian_tflops": round(flops / (el / a.steps) / 1e12, 2),
+                      "kernels": {n: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1])} for n, v in kt.items()},
+                      "rmse": [round(r.rmse, 6) for r in rep], "gen_seconds": round(gen_s, 2)}), flush=True)
+    s.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +94,9 @@ def main() -> None:
     ap.add_argument("--panel-rows", type=int, default=0, help="LDS panel size (0 auto, -1 off)")
     ap.add_argument("--wg-waves", type=int, default=0, help="waves per workgroup of the panel kernel (0 = 8)")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N = 1 only: run through the sharded code path with a 1-rank RCCL communicator")
+    ap.add_argument("--solver", choices=["ccd", "als"], default="ccd", help="als: report ALS iteration time instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
     a = ap.parse_args()
@@ -105,10 +133,14 @@ def main() -> None:
         uid = [mfx.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         comm = mfx.Comm(uid[0], rank, world, local_rank)
+    if world == 1 and a.force_comm:
+        comm = mfx.Comm(mfx.Comm.unique_id(), 0, 1, local_rank)
     nnz_global, ntest_global = int(nnz_tot[0]), int(nnz_tot[1])
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 
+    if a.solver == "als":
+        return bench_als(a, d, mfx, synth_torch, torch, gen_s)
     p = mfx.parameter()
     p.k, p.lambda_, p.maxinneriter, p.device = a.k, a.lam, a.inner, local_rank
     p.schedule, p.kernel_variant, p.tiles_per_span = a.schedule, a.variant, a.tiles

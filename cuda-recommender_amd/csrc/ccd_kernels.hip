@@ -156,7 +156,6 @@ struct FlatArgs {
     float* carry_g;
     float* carry_h;
     int add;
-    int dbg;
 };
 
 template <int MODE> struct ModeTraits;
@@ -298,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         for (int e = 0; e < 4; ++e) ga[e] = LDS ? slice[ids[e]] : gather[ids[e]];
         float vo[4], gc[4], hc[4];
 
-        if (cur1_next == cur1 || (a.dbg & 1)) {
+        if (cur1_next == cur1) {
             // ---- no segment starts in this tile: everything belongs to the open segment ----
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -319,12 +318,12 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                     // element e's rank + 1 = r1 + heads among elements 0..e of this lane (>= 1 always:
                     // the very first stored element is a head)
                     const uint32_t re1 = r1 + (uint32_t) __popc(nib & ((2u << e) - 1u));
-                    ps = (a.dbg & 2) ? pcur : fetch_ps(re1 - 1);
+                    ps = fetch_ps(re1 - 1);
                 }
                 element_op<MODE>(vs[e], ga[e], ps, a.add, vo[e], gc[e], hc[e]);
                 if (partial && e0 + e >= a.nnz) { gc[e] = 0.f; hc[e] = 0.f; }
             }
-            if (TR::kDot && !(a.dbg & 4)) {
+            if constexpr (TR::kDot) {
                 // carry-in: the open segment's sum so far, as a wave-uniform value
                 float cin_g, cin_h;
                 if (open_spread) {
@@ -629,8 +628,6 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
     a.tiles_per_span = s.tiles_per_span; a.panel_rows = s.panel_rows; a.gather_len = s.gather_len; a.nne = s.nne;
     a.nnz = s.nnz; a.gather = gather; a.perseg = perseg; a.gpart = s.gpart; a.hpart = s.hpart;
     a.carry_g = s.carry_g; a.carry_h = s.carry_h; a.add = add;
-    static const int dbg = getenv("MFX_DBG") ? atoi(getenv("MFX_DBG")) : 0;
-    a.dbg = dbg;
     switch (mode) {
         case FM_SWEEP: return launch_flat_mode<FM_SWEEP>(s, a, st);
         case FM_RESID: return launch_flat_mode<FM_RESID>(s, a, st);

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Copies the judged summaries of tools/prof_r01_final.sh from gpurun_out/final into profiles/
+and derives profiles/traffic.json (HBM bytes per launch of the fused passes, read by bench.py)."""
+import csv, glob, json, os, subprocess, sys
+csv.field_size_limit(1 << 30)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst, tag = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles"), sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs(dst, exist_ok=True)
+rows = []
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    rd = list(csv.reader(open(f)))
+    rows = [rd[0]] + [r for r in rd[1:] if "mfx" in r[0]]
+csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w")).writerows(rows)
+with open(os.path.join(dst, f"{tag}_pmc.txt"), "w") as out:
+    for d in ("fetch", "write", "l2", "sq"):
+        out.write(f"== rocprofv3 --pmc pass: {d}\n")
+        out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parse_pmc.py"), os.path.join(src, d), "mfx"],
+                                 capture_output=True, text=True).stdout)
+line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith("{")][-1]
+open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
+als = [l for l in open(os.path.join(src, "bench_als.log")) if l.startswith("{")]
+if als:
+    open(os.path.join(dst, f"{tag}_bench_als.json"), "w").write(als[-1])
+bench = json.loads(line)
+Z = int(bench["config"]["nnz_global"])
+def mean(dirname, kern, ctr):
+    s = n = 0
+    for f in glob.glob(os.path.join(src, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                s += float(r["Counter_Value"]); n += 1
+    return s / n if n else None
+traffic = {}
+for name, kern in (("ccd_fused_csc_pass", "k_flat<2"), ("ccd_fused_csr_pass", "k_flat<3")):
+    fetch_kb, write_kb = mean("fetch", kern, "FETCH_SIZE"), mean("write", kern, "WRITE_SIZE")
+    if fetch_kb is None or write_kb is None:
+        continue
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+    # half of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B stores.
+    traffic[name] = {"nnz": Z, "fetch_size_kib_raw": fetch_kb, "write_size_kib_raw": write_kb,
+                     "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
+                     "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE half-count correction"}
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(open(os.path.join(dst, f"{tag}_pmc.txt")).read())
+print(json.dumps(traffic, indent=1))
