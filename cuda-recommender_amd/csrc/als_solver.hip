@@ -51,7 +51,7 @@ template <int NT>
 __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], float* lds,
                            const AlsArgs& a, uint32_t seg) {
     constexpr int KP = 32 * NT;
-    constexpr int LD = KP + 1;
+    constexpr int LD = KP + 4;  // rows 16-B aligned (ds_read_b128) and 4 banks apart: 16 rows x 4 banks = conflict-free
     const uint32_t lane = threadIdx.x & 63, c31 = lane & 31, h = lane >> 5;
     const int k = (int) a.k;
     float* L = lds;
@@ -95,7 +95,20 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
             float sum = 0.f;
             if (j < k) {
                 sum = L[j * LD + i];
-                for (int q = i - 1; q >= 0; --q) sum = __fsub_rn(sum, __fmul_rn(L[i * LD + q], L[j * LD + q]));
+                // reference order: q = i-1 down to 0.  Four columns per ds_read_b128 (row i is a
+                // broadcast read, row j is lane-strided and conflict-free); the subtractions stay
+                // sequential and unfused so that the factor matches src/ALS.cpp:9-12 operation for
+                // operation.
+                int q = i - 1;
+                for (; (q & 3) != 3 && q >= 0; --q) sum = __fsub_rn(sum, __fmul_rn(L[i * LD + q], L[j * LD + q]));
+                for (; q >= 3; q -= 4) {
+                    const float4 a = *reinterpret_cast<const float4*>(&L[i * LD + q - 3]);
+                    const float4 b = *reinterpret_cast<const float4*>(&L[j * LD + q - 3]);
+                    sum = __fsub_rn(sum, __fmul_rn(a.w, b.w));
+                    sum = __fsub_rn(sum, __fmul_rn(a.z, b.z));
+                    sum = __fsub_rn(sum, __fmul_rn(a.y, b.y));
+                    sum = __fsub_rn(sum, __fmul_rn(a.x, b.x));
+                }
             }
             if (j0 == i) {  // lane 0 holds the pivot of this row
                 const float piv = __shfl(sum, 0, 64);
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
 #pragma unroll
     for (int I = 0; I < NT; ++I) bacc[I] = 0.f;
 
-    constexpr int U = 4;  // gathered row pairs in flight per wave
+    constexpr int U = 8;  // gathered row pairs in flight per wave
     for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 2 * U) {
         float av[U][NT], rv[U];
 #pragma unroll
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(64) void k_als_reduce(AlsArgs a) {
 template <int NT>
 int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
     constexpr int KP = 32 * NT;
-    const size_t lds_bytes = ((size_t) KP * (KP + 1) + KP) * sizeof(float);
+    const size_t lds_bytes = ((size_t) KP * (KP + 4) + KP) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 48 * 1024) {
         MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_gram<NT>),
