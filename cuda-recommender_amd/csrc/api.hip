@@ -285,6 +285,9 @@ int mfx_comm_unique_id(void* id_out) {
 int mfx_comm_create(mfx_comm_t* out, const void* id, int rank, int nranks, int device) {
     return comm_create(out, id, rank, nranks, device);
 }
+int mfx_comm_create_local(mfx_comm_t* out, int group, int rank, int nranks, int device) {
+    return comm_create_local(out, group, rank, nranks, device);
+}
 int mfx_comm_rank(mfx_comm_t c) { return c ? c->rank : -1; }
 int mfx_comm_size(mfx_comm_t c) { return c ? c->nranks : 0; }
 int mfx_comm_destroy(mfx_comm_t c) { return comm_destroy(c); }

@@ -5,8 +5,11 @@
 
 #include "common.hpp"
 
+namespace mfx { struct LocalGroup; }
+
 struct mfx_comm_s {
-    void* nccl = nullptr;  // ncclComm_t
+    void* nccl = nullptr;  // ncclComm_t (RCCL communicator), or
+    mfx::LocalGroup* local = nullptr;  // in-process loopback group (threads of one process, host-staged)
     int rank = 0;
     int nranks = 1;
     int device = 0;
@@ -15,6 +18,7 @@ struct mfx_comm_s {
 namespace mfx {
 int comm_unique_id(void* id_out);
 int comm_create(mfx_comm_s** out, const void* id, int rank, int nranks, int device);
+int comm_create_local(mfx_comm_s** out, int group, int rank, int nranks, int device);
 int comm_destroy(mfx_comm_s* c);
 // In-place sum all-reduce on `st`.
 int comm_allreduce_f32(mfx_comm_s* c, float* buf, size_t count, hipStream_t st);

@@ -15,7 +15,24 @@ static void runCUDA(SparseMatrix& R, TestData& T, MatData& W, MatData& H, parame
     else kernel_wrapper_ccdpp_NV(R, T, W, H, parameters);
 }
 
+// mfx_train -predict <model> <test.txt> <output>: the file-based scoring step the reference stubs
+// out (src/main.cpp:146-149); the model must have been written row-major (rows x k), i.e. by an
+// ALS run with -save, or converted.
+static int predict_mode(int argc, char** argv) {
+    if (argc != 5) { fprintf(stderr, "usage: mfx_train -predict model_file test_file output_file\n"); return EXIT_FAILURE; }
+    FILE* model = fopen(argv[2], "rb");
+    FILE* test = fopen(argv[3], "r");
+    if (!model) { fprintf(stderr, "can't open model file %s\n", argv[2]); return EXIT_FAILURE; }
+    if (!test) { fprintf(stderr, "can't open test file %s\n", argv[3]); return EXIT_FAILURE; }
+    FILE* out = fopen(argv[4], "w");
+    if (!out) { fprintf(stderr, "can't open output file %s\n", argv[4]); return EXIT_FAILURE; }
+    calculate_rmse_from_file(model, test, out);
+    fclose(model); fclose(test); fclose(out);
+    return EXIT_SUCCESS;
+}
+
 int main(int argc, char* argv[]) {
+    if (argc > 1 && !strcmp(argv[1], "-predict")) return predict_mode(argc, argv);
     auto t_start = std::chrono::high_resolution_clock::now();
     parameter param = parse_command_line(argc, argv);
     const char* save_path = nullptr;

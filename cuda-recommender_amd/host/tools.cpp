@@ -229,3 +229,28 @@ MatData load_mat_t(FILE* fp, bool row_major) {
         for (long j = 0; j < n; ++j) (row_major ? A[i][j] : A[j][i]) = buf[(size_t) i * n + j];
     return A;
 }
+
+double calculate_rmse_from_file(FILE* model_fp, FILE* test_fp, FILE* output_fp) {
+    auto t0 = std::chrono::high_resolution_clock::now();
+    rewind(model_fp);
+    MatData W = load_mat_t(model_fp, true);
+    MatData H = load_mat_t(model_fp, true);
+    const size_t rank = W[0].size();
+    if (rank == 0 || H[0].size() != rank) die("Matrix is empty!");
+    int i, j;
+    double v, acc = 0;
+    size_t n = 0;
+    while (fscanf(test_fp, "%d %d %lf", &i, &j, &v) == 3) {
+        if (i < 1 || j < 1 || (size_t) i > W.size() || (size_t) j > H.size()) die("test file: index out of range (indices are 1-based)");
+        double pred = 0;
+        for (size_t t = 0; t < rank; ++t) pred += W[i - 1][t] * H[j - 1][t];
+        acc += (pred - v) * (pred - v);
+        ++n;
+        if (output_fp) fprintf(output_fp, "%lf\n", pred);
+    }
+    if (n == 0) exit(EXIT_FAILURE);
+    const double rmse = std::sqrt(acc / (double) n);
+    auto t1 = std::chrono::high_resolution_clock::now();
+    printf("[FINAL INFO] Test RMSE = %f. Calculated in %lfs\n", rmse, std::chrono::duration<double>(t1 - t0).count());
+    return rmse;
+}

@@ -17,3 +17,6 @@ void exit_with_help();
 // reference: save_mat_t / load_mat_t model format (src/tools.cpp:90-153): [long m][long n][m*n f32 row-major]
 void save_mat_t(const MatData& A, FILE* fp, bool row_major = true);
 MatData load_mat_t(FILE* fp, bool row_major = true);
+// reference: calculate_rmse_from_file (src/extras.cpp:143-180): model = W then H (row-major, rows x k),
+// test file = text "i j v" with 1-BASED indices, one prediction per line written to output_fp.
+double calculate_rmse_from_file(FILE* model_fp, FILE* test_fp, FILE* output_fp);

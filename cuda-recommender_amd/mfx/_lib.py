@@ -86,6 +86,7 @@ SIGNATURES = {
                                C.c_float, C.c_int]),
     "mfx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mfx_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mfx_comm_create_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "mfx_comm_rank": (C.c_int, [C.c_void_p]),
     "mfx_comm_size": (C.c_int, [C.c_void_p]),
     "mfx_comm_destroy": (C.c_int, [C.c_void_p]),

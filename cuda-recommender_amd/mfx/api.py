@@ -289,10 +289,13 @@ class Comm:
     """RCCL communicator (one process per GPU).  `uid` is the 128-byte id from Comm.unique_id()
     on rank 0, shipped to the other ranks by the caller."""
 
-    def __init__(self, uid: bytes, rank: int, nranks: int, device: int):
+    def __init__(self, uid: Optional[bytes], rank: int, nranks: int, device: int, local_group: Optional[int] = None):
         self.handle = C.c_void_p()
-        buf = C.create_string_buffer(bytes(uid), L.MFX_COMM_ID_BYTES)
-        L.check(L.lib().mfx_comm_create(C.byref(self.handle), buf, rank, nranks, device))
+        if local_group is not None:  # in-process loopback group (threads of one process), see mfx.h
+            L.check(L.lib().mfx_comm_create_local(C.byref(self.handle), int(local_group), rank, nranks, device))
+        else:
+            buf = C.create_string_buffer(bytes(uid), L.MFX_COMM_ID_BYTES)
+            L.check(L.lib().mfx_comm_create(C.byref(self.handle), buf, rank, nranks, device))
         self.rank, self.nranks = rank, nranks
 
     @staticmethod

@@ -203,6 +203,11 @@ int mfx_als_half(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t*
 #define MFX_COMM_ID_BYTES 128
 int mfx_comm_unique_id(void* id_out /* MFX_COMM_ID_BYTES */);
 int mfx_comm_create(mfx_comm_t* out, const void* id, int rank, int nranks, int device);
+/* In-process loopback communicator: the `nranks` ranks of `group` are threads of ONE process (each
+ * driving its own solver, on the same or on different devices); collectives are staged through
+ * host memory and summed in rank order.  Slow by design -- it exists to run the sharded solver path
+ * through the real kernels where RCCL cannot (two ranks on one GPU); production uses mfx_comm_create. */
+int mfx_comm_create_local(mfx_comm_t* out, int group, int rank, int nranks, int device);
 int mfx_comm_rank(mfx_comm_t c);
 int mfx_comm_size(mfx_comm_t c);
 int mfx_comm_destroy(mfx_comm_t c);

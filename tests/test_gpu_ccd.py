@@ -259,3 +259,44 @@ def test_sharded_path_single_rank_rccl(mfx, medium):
     s1.set_factors(W0.copy()); r1 = s1.iterate(2); f1 = s1.get_factors(); s1.close(); comm.close()
     assert np.array_equal(bits(f0[0]), bits(f1[0])) and np.array_equal(bits(f0[1]), bits(f1[1]))
     assert [r.rmse for r in r0] == [r.rmse for r in r1]
+
+
+@pytest.mark.parametrize("nshards,schedule,variant,T", [(2, 1, 1, 1), (3, 1, 1, 2), (4, 0, 1, 1), (2, 0, 0, 1)])
+def test_sharded_solve_multi_rank_loopback(mfx, orc, medium, nshards, schedule, variant, T):
+    """N user-row-block shards, one solver per shard (threads of this process, loopback communicator:
+    RCCL refuses two ranks on one GPU), through the real HIP kernels: local (g,h) partials, all-reduce,
+    division by lambda * GLOBAL |Omega_c|, replicated H, sharded W, global RMSE.  Must match the
+    unsharded CPU oracle like the single-GPU solve does."""
+    import threading
+    d, k, lam, t = medium, 12, 0.05, 2
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, *_ = orc.ccdr1(d, W0, k, lam, t, T, orc.max_threads())
+    bounds = mfx.partition_rows(d, nshards)
+    gcnt = np.ascontiguousarray(np.diff(d.csc_col_ptr.astype(np.int64)).astype(np.uint32))
+    out, errs = [None] * nshards, []
+    group = 1000 + nshards * 10 + schedule * 2 + variant
+
+    def run(r):
+        try:
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            shard = mfx.extract_shard(d, lo, hi)
+            comm = mfx.Comm(None, r, nshards, 0, local_group=group)
+            s = mfx.CcdSolver(shard, mfx.test_data_of(shard), _params(mfx, k, lam, t, T, schedule, variant),
+                              comm=comm, global_col_nnz=gcnt, global_test_nnz=d.nnz_test)
+            s.set_factors(np.ascontiguousarray(W0[:, lo:hi]))
+            rep = s.iterate(t)
+            out[r] = (s.get_factors(), [x.rmse for x in rep])
+            s.close(); comm.close()
+        except Exception as e:  # surface failures instead of dead-locking the other ranks' rendezvous
+            errs.append(e)
+            raise
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nshards)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not errs and all(o is not None for o in out), errs
+    W = np.concatenate([o[0][0] for o in out], axis=1)
+    assert relerr(W, Wr) < 2e-3
+    for (Wl, Hl), rm in out:
+        assert relerr(Hl, Hr) < 2e-3 and np.all(np.abs(np.array(rm) - rmse_ref) < 1e-4)
+    assert all(np.array_equal(bits(out[0][0][1]), bits(o[0][1])) for o in out)  # H replicas identical

@@ -182,3 +182,23 @@ def test_model_file_format_roundtrip(tmp_path):
     raw = open(tmp_path / "m.bin", "rb").read()
     m, n = struct.unpack("<qq", raw[:16])
     assert (m, n) == (3, 4) and np.array_equal(np.frombuffer(raw[16:], np.float32).reshape(3, 4), W)
+
+
+def test_cli_predict_from_model_file(mfx, tmp_path):
+    """mfx_train -predict: calculate_rmse_from_file semantics (src/extras.cpp:143-180): row-major model,
+    1-based text test file, one prediction per output line."""
+    import struct
+    rng = np.random.default_rng(1)
+    W, H = rng.standard_normal((5, 3)).astype(np.float32), rng.standard_normal((4, 3)).astype(np.float32)
+    with open(tmp_path / "model", "wb") as f:
+        for M in (W, H):
+            f.write(struct.pack("<qq", *M.shape)); f.write(M.tobytes())
+    trip = [(1, 1, 3.0), (5, 4, 1.5), (2, 3, 4.0)]
+    (tmp_path / "test.txt").write_text("".join(f"{i} {j} {v}\n" for i, j, v in trip))
+    r = _run_cli(["-predict", str(tmp_path / "model"), str(tmp_path / "test.txt"), str(tmp_path / "out.txt")])
+    assert r.returncode == 0, r.stderr
+    pred = np.array([float(x) for x in (tmp_path / "out.txt").read_text().split()])
+    want = np.array([float(np.dot(W[i - 1].astype(np.float64), H[j - 1].astype(np.float64))) for i, j, _ in trip])
+    assert np.allclose(pred, want, atol=1e-5)
+    rmse = float(np.sqrt(np.mean((want - np.array([v for *_, v in trip])) ** 2)))
+    assert f"[FINAL INFO] Test RMSE = {rmse:f}" in r.stdout
