@@ -119,8 +119,11 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     o.spans_per_wg = p.wg_waves > 0 ? (uint32_t) p.wg_waves : 16;
     o.panel_rows = 0;
     if (need_plain || p.panel_rows < 0) return o;
-    // 64 KB of LDS per workgroup: 8 KB for the staged per-segment operands, the rest for the slice
-    uint32_t pr = p.panel_rows > 0 ? (uint32_t) p.panel_rows : (56u * 1024u) / elem_bytes - 1;
+    // 64 KB of LDS per workgroup (two 1024-thread workgroups per CU): 8 KB for the staged per-segment
+    // operands, 56 KB for the slice.  Measured on the Netflix shape (tools/sweep_r01_j.sh): slices of
+    // 40/48/56/64/72 KB give 30.1/29.9/28.0/29.1/28.4 ms per outer iteration.
+    constexpr uint32_t slice_kb = 56;
+    uint32_t pr = p.panel_rows > 0 ? (uint32_t) p.panel_rows : (slice_kb * 1024u) / elem_bytes - 1;
     if (pr >= G) pr = G;  // the whole gathered vector fits: one panel
     const uint64_t npanels = (G + pr - 1) / pr;
     const double mean_vseg = (double) nnz / ((double) npanels * (double) (nseg ? nseg : 1));
