@@ -111,7 +111,7 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
                 }
             }
             if (j0 == i) {  // lane 0 holds the pivot of this row
-                const float piv = __shfl(sum, 0, 64);
+                const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sum)));
                 if (lane == 0 && !(piv > 0.f)) atomicAdd(a.spd_fail, 1u);
                 p = sqrtf(piv);
             }
@@ -124,7 +124,7 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
     float z1 = (NT > 2 && lane + 64 < (uint32_t) k) ? bv[lane + 64] : 0.f;
     for (int i = 0; i < k; ++i) {
         const float src = (NT > 2 && i >= 64) ? z1 : z0;
-        const float zi = __shfl(src, i & 63, 64) / L[i * LD + i];
+        const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), i & 63)) / L[i * LD + i];
         if ((int) lane == i) z0 = zi;
         if (NT > 2 && (int) lane + 64 == i) z1 = zi;
         if ((int) lane > i && (int) lane < k) z0 = __fsub_rn(z0, __fmul_rn(L[lane * LD + i], zi));
@@ -133,7 +133,7 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
     // back substitution L^T y = z
     for (int i = k - 1; i >= 0; --i) {
         const float src = (NT > 2 && i >= 64) ? z1 : z0;
-        const float yi = __shfl(src, i & 63, 64) / L[i * LD + i];
+        const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), i & 63)) / L[i * LD + i];
         if ((int) lane == i) z0 = yi;
         if (NT > 2 && (int) lane + 64 == i) z1 = yi;
         if ((int) lane < i) z0 = __fsub_rn(z0, __fmul_rn(L[i * LD + lane], yi));
@@ -166,20 +166,36 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
     for (int I = 0; I < NT; ++I) bacc[I] = 0.f;
 
     constexpr int U = 8;  // gathered row pairs in flight per wave
+    // Two dependent memory round trips per step (index -> factor row).  The indices and ratings of
+    // step s+1 are fetched before the MFMAs of step s, so only the row gather's latency is exposed.
+    uint32_t row_n[U];
+    float rv_n[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t q = it.lo + 2 * u + h;
+        const bool ok = q < it.hi;
+        row_n[u] = ok ? a.idx[q] : 0u;
+        rv_n[u] = ok ? a.val[q] : 0.f;
+    }
     for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 2 * U) {
         float av[U][NT], rv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + 2 * u + h;
-            const bool ok = q < it.hi;
-            const uint32_t row = ok ? a.idx[q] : 0u;
-            rv[u] = ok ? a.val[q] : 0.f;
-            const float* x = a.X + (size_t) row * k;
+            const bool ok = q0 + 2 * u + h < it.hi;
+            rv[u] = rv_n[u];
+            const float* x = a.X + (size_t) row_n[u] * k;
 #pragma unroll
             for (int I = 0; I < NT; ++I) {
                 const uint32_t col = I * 32 + c31;
                 av[u][I] = (ok && col < k) ? x[col] : 0.f;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 2 * U + 2 * u + h;
+            const bool ok = q < it.hi;
+            row_n[u] = ok ? a.idx[q] : 0u;
+            rv_n[u] = ok ? a.val[q] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
