@@ -24,6 +24,20 @@
 namespace mfx {
 namespace {
 
+// unfused multiply / subtract (HIP's __fmul_rn is a plain `*` and would be contracted into v_fma)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 struct AlsArgs {
@@ -83,7 +97,7 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
         for (int e = (int) lane; e < k * k; e += 64) a.gram_out[e] = L[(e / k) * LD + (e % k)];
         return;
     }
-    for (int i = (int) lane; i < k; i += 64) L[i * LD + i] = __fadd_rn(L[i * LD + i], a.lambda);
+    for (int i = (int) lane; i < k; i += 64) L[i * LD + i] = add_rn(L[i * LD + i], a.lambda);
     __syncthreads();
 
     // Left-looking Cholesky on the lower triangle, row i of the reference's loop at a time:
@@ -100,14 +114,14 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
                 // sequential and unfused so that the factor matches src/ALS.cpp:9-12 operation for
                 // operation.
                 int q = i - 1;
-                for (; (q & 3) != 3 && q >= 0; --q) sum = __fsub_rn(sum, __fmul_rn(L[i * LD + q], L[j * LD + q]));
+                for (; (q & 3) != 3 && q >= 0; --q) sum = sub_rn(sum, mul_rn(L[i * LD + q], L[j * LD + q]));
                 for (; q >= 3; q -= 4) {
                     const float4 a = *reinterpret_cast<const float4*>(&L[i * LD + q - 3]);
                     const float4 b = *reinterpret_cast<const float4*>(&L[j * LD + q - 3]);
-                    sum = __fsub_rn(sum, __fmul_rn(a.w, b.w));
-                    sum = __fsub_rn(sum, __fmul_rn(a.z, b.z));
-                    sum = __fsub_rn(sum, __fmul_rn(a.y, b.y));
-                    sum = __fsub_rn(sum, __fmul_rn(a.x, b.x));
+                    sum = sub_rn(sum, mul_rn(a.w, b.w));
+                    sum = sub_rn(sum, mul_rn(a.z, b.z));
+                    sum = sub_rn(sum, mul_rn(a.y, b.y));
+                    sum = sub_rn(sum, mul_rn(a.x, b.x));
                 }
             }
             if (j0 == i) {  // lane 0 holds the pivot of this row
@@ -127,8 +141,8 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
         const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), i & 63)) / L[i * LD + i];
         if ((int) lane == i) z0 = zi;
         if (NT > 2 && (int) lane + 64 == i) z1 = zi;
-        if ((int) lane > i && (int) lane < k) z0 = __fsub_rn(z0, __fmul_rn(L[lane * LD + i], zi));
-        if (NT > 2 && (int) lane + 64 > i && (int) lane + 64 < k) z1 = __fsub_rn(z1, __fmul_rn(L[(lane + 64) * LD + i], zi));
+        if ((int) lane > i && (int) lane < k) z0 = sub_rn(z0, mul_rn(L[lane * LD + i], zi));
+        if (NT > 2 && (int) lane + 64 > i && (int) lane + 64 < k) z1 = sub_rn(z1, mul_rn(L[(lane + 64) * LD + i], zi));
     }
     // back substitution L^T y = z
     for (int i = k - 1; i >= 0; --i) {
@@ -136,8 +150,8 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
         const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), i & 63)) / L[i * LD + i];
         if ((int) lane == i) z0 = yi;
         if (NT > 2 && (int) lane + 64 == i) z1 = yi;
-        if ((int) lane < i) z0 = __fsub_rn(z0, __fmul_rn(L[i * LD + lane], yi));
-        if (NT > 2 && (int) lane + 64 < i) z1 = __fsub_rn(z1, __fmul_rn(L[i * LD + lane + 64], yi));
+        if ((int) lane < i) z0 = sub_rn(z0, mul_rn(L[i * LD + lane], yi));
+        if (NT > 2 && (int) lane + 64 < i) z1 = sub_rn(z1, mul_rn(L[i * LD + lane + 64], yi));
     }
     float* y = a.Y + (size_t) seg * k;
     if ((int) lane < k) y[lane] = z0;

@@ -76,9 +76,20 @@ __device__ __forceinline__ void seg_scan2(float& xg, float& xh, uint32_t lane, u
 
 // Unfused multiply-then-add/sub, like the reference CPU build (no FMA contraction), so that the
 // residual update is bit-identical to src/CCD.cpp:25,36 given identical operands.
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+// (HIP's __fmul_rn/__fadd_rn are plain `*`/`+` and get contracted into v_fma under hipcc's default
+// -ffp-contract=fast; the pragma strips the `contract` flag from these operations so they cannot.)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Variant 0: one wavefront per segment.
