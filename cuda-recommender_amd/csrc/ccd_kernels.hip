@@ -272,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     }
     IdxVec id_n = __builtin_nontemporal_load(idx4);
     f32x4 v_n = __builtin_nontemporal_load(val4);
-    uint32_t fl_n = flw[0], hp_n = hpw[0];
+    uint32_t fl_n = flw[0], hp_n = hpw[0], hp_nn = hpw[8];
     const uint32_t rank_base = __builtin_amdgcn_readfirstlane(hp_n);  // heads before this span
     uint32_t cur1 = rank_base;  // (rank of the segment open at the current position) + 1, wave-uniform
     P pcur{};
@@ -286,15 +286,18 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         const IdxVec id = id_n;
         const f32x4 v = v_n;
         const uint32_t fl = fl_n, hp = hp_n;
-        // next tile's streams and head metadata, one tile ahead (the metadata arrays carry 8 spare
-        // words, so reading one tile past the last span is in bounds and gives heads_total)
+        // heads before the NEXT tile decide right now whether this tile is segmented, so that count
+        // is fetched two tiles ahead (it arrived during the previous iteration: no wait here);
+        // streams and head bits run one tile ahead.  The metadata arrays carry 16 spare words, so
+        // reading two tiles past the last span stays in bounds (and yields heads_total).
+        const uint32_t cur1_next = __builtin_amdgcn_readfirstlane(hp_nn);
+        hp_n = hp_nn;
         if (tile + 1 < ntiles) {
             id_n = __builtin_nontemporal_load(idx4 + (tile + 1) * 64);
             v_n = __builtin_nontemporal_load(val4 + (tile + 1) * 64);
         }
         fl_n = flw[(tile + 1) * 8];
-        hp_n = hpw[(tile + 1) * 8];
-        const uint32_t cur1_next = __builtin_amdgcn_readfirstlane(hp_n);  // heads before the next tile
+        hp_nn = hpw[(tile + 2) * 8];
         const uint64_t base = start + (uint64_t) tile * kTileElems;
         // plain layout only: the tile that straddles nnz needs its padding masked; with LDS panels
         // padding gathers the zero slot and contributes exact zeros
@@ -441,18 +444,42 @@ struct GatherPartsArgs {
 };
 
 // (g, h) of real segment c over panels p0, p0 + stride, ...: each virtual segment = part + carries.
+// The lookups of one panel are a chain of dependent loads (rank -> part, pointers -> carries), so
+// they are issued for kBatch panels at a time: two memory round trips per batch instead of two per
+// panel.  The additions stay in panel order.
 __device__ __forceinline__ void segment_sums(const GatherPartsArgs& a, uint32_t c, uint32_t p0, uint32_t stride,
                                              float& g, float& h) {
+    constexpr int kBatch = 5;
     g = 0.f;
     h = 0.f;
-    for (uint32_t p = p0; p < a.npanels; p += stride) {
-        const size_t v = (size_t) p * a.nseg + c;
-        const int32_t r = a.rank_of_seg[v];
-        if (r >= 0) {
-            float pg = a.gpart[r], ph = a.hpart[r];
-            add_carries(a.ptr_v[v], a.ptr_v[v + 1], a.span_len, a.cg, a.ch, pg, ph);
-            g += pg;
-            h += ph;
+    for (uint32_t pb = p0; pb < a.npanels; pb += stride * kBatch) {
+        int32_t r[kBatch];
+        uint32_t lo[kBatch], hi[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            const uint32_t p = pb + q * stride;
+            r[q] = -1;
+            lo[q] = hi[q] = 0;
+            if (p < a.npanels) {
+                const size_t v = (size_t) p * a.nseg + c;
+                r[q] = a.rank_of_seg[v];
+                lo[q] = a.ptr_v[v];
+                hi[q] = a.ptr_v[v + 1];
+            }
+        }
+        float pg[kBatch], ph[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            pg[q] = r[q] >= 0 ? a.gpart[r[q]] : 0.f;
+            ph[q] = r[q] >= 0 ? a.hpart[r[q]] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) {
+            if (r[q] >= 0) {
+                add_carries(lo[q], hi[q], a.span_len, a.cg, a.ch, pg[q], ph[q]);
+                g += pg[q];
+                h += ph[q];
+            }
         }
     }
 }

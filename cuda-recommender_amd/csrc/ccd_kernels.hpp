@@ -31,8 +31,8 @@ struct SegStreamDev {
     const uint32_t* idx = nullptr;             // [padded nnz] gathered index (plain layout)
     const uint16_t* idx16 = nullptr;           // [padded nnz] panel-local gathered index (LDS panels)
     float* val = nullptr;                      // [padded nnz] residual copy, updated in place
-    const uint32_t* flags32 = nullptr;         // [padded nnz / 32 + 8] head bits
-    const uint32_t* hpre = nullptr;            // [padded nnz / 32 + 8] heads before each word
+    const uint32_t* flags32 = nullptr;         // [padded nnz / 32 + 16] head bits
+    const uint32_t* hpre = nullptr;            // [padded nnz / 32 + 16] heads before each word
     uint32_t max_wg_ranks = 0;                 // most ranks any workgroup chunk touches
     const int32_t* rank_of_seg = nullptr;      // [npanels*nseg]
     const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id

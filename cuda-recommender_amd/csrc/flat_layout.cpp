@@ -100,7 +100,7 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
 
     // 4. head flags, ranks and per-word head prefix counts over the virtual segments
     const size_t nwords = L.padded_nnz / 32;
-    L.flags32.assign(nwords + 8, 0);
+    L.flags32.assign(nwords + 16, 0);  // two tiles of spare words: the kernel reads metadata two tiles ahead
     L.rank_of_seg.assign(nv, -1);
     L.seg_of_rank.clear();
     L.seg_of_rank.reserve(std::min<size_t>(nv, (size_t) nnz + P));
@@ -113,9 +113,9 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
         }
     }
     L.nne = (uint32_t) L.seg_of_rank.size();
-    L.hpre.assign(nwords + 8, 0);
+    L.hpre.assign(nwords + 16, 0);
     uint32_t run = 0;
-    for (size_t w = 0; w < nwords + 8; ++w) {
+    for (size_t w = 0; w < nwords + 16; ++w) {
         L.hpre[w] = run;
         run += (uint32_t) __builtin_popcount(L.flags32[w]);
     }

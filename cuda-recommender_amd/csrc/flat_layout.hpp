@@ -52,8 +52,8 @@ struct FlatLayoutHost {
     uint32_t max_wg_ranks = 0;    // most ranks any workgroup chunk touches (incl. the one open at its start)
     std::vector<uint32_t> ptr_v;           // [npanels*nseg + 1]
     std::vector<uint32_t> seg_cnt;         // [nseg] real entries per segment
-    std::vector<uint32_t> flags32;         // [padded_nnz / 32 + 8] head bits (tail words zero)
-    std::vector<uint32_t> hpre;            // [padded_nnz / 32 + 8] heads before each word (tail = nne)
+    std::vector<uint32_t> flags32;         // [padded_nnz / 32 + 16] head bits (tail words zero)
+    std::vector<uint32_t> hpre;            // [padded_nnz / 32 + 16] heads before each word (tail = nne)
     std::vector<int32_t> rank_of_seg;      // [npanels*nseg], -1 for an empty virtual segment
     std::vector<uint32_t> seg_of_rank;     // [nne] REAL segment id of each rank
     std::vector<uint32_t> wg_panel;        // [nspans / spans_per_wg] (panel layout only)
