@@ -97,6 +97,9 @@ def main() -> None:
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1 only: run through the sharded code path with a 1-rank RCCL communicator")
     ap.add_argument("--solver", choices=["ccd", "als"], default="ccd", help="als: report ALS iteration time instead")
+    ap.add_argument("--no-event-pass", action="store_true",
+                    help="skip the second, event-bracketed pass (use under rocprofv3 --kernel-trace: the "
+                         "event packets between launches otherwise end up inside its kernel durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
     a = ap.parse_args()
@@ -174,10 +177,12 @@ def main() -> None:
     value = nnz_global / (elapsed / a.steps)
 
     # ---------------- roofline: same K steps again, every launch bracketed by HIP events ------------
-    solver.set_profile(True)
-    solver.iterate(a.steps, with_rmse=False)
-    ktimes = solver.kernel_times()
-    solver.set_profile(False)
+    ktimes = {}
+    if not a.no_event_pass:
+        solver.set_profile(True)
+        solver.iterate(a.steps, with_rmse=False)
+        ktimes = solver.kernel_times()
+        solver.set_profile(False)
     m, n, Z = int(d["rows"]), int(d["cols"]), nnz_local
     flags = Z / 8.0
     # algorithmic bytes per launch (DESIGN.md "bytes per kernel"): idx + val read + val write per

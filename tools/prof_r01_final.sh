@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT; O=gpurun_out/final; rm -rf $O; mkdir -p $O
 python3 bench.py --steps 3 --warmup 1 > $O/bench.log 2>&1; echo "bench exit $?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1 || echo "stats failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-event-pass > $O/stats.log 2>&1 || echo "stats failed"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/fetch.log 2>&1 || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1 || echo "write failed"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/l2 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/l2.log 2>&1 || echo "l2 failed"
