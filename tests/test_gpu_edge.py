@@ -1,0 +1,119 @@
+"""GPU edge cases through the C ABI: degenerate shapes and parameters the reference's code paths
+imply (empty segments -> 0, src/CCD.cpp:8; zero rows in ALS, src/ALS.cpp:151-157) plus the
+limits of this implementation's layouts (panel boundaries, 16-bit local indices, rank windows)."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mfx():
+    import mfx as m
+    assert m.device_count() >= 1
+    return m
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _p(mfx, k, t=2, T=1, **kw):
+    p = mfx.parameter()
+    p.k, p.lambda_, p.maxiter, p.maxinneriter = k, 0.05, t, T
+    for a, b in kw.items():
+        setattr(p, a, b)
+    return p
+
+
+def _check(mfx, orc, d, k, t=2, T=1, tol=2e-3, **kw):
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, *_ = orc.ccdr1(d, W0, k, 0.05, t, T, 2)
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, k, t, T, **kw))
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    W, H = s.get_factors()
+    csc, csr = s.get_residual(d.nnz)
+    s.close()
+    scale = max(1e-6, float(np.abs(Wr).max()), float(np.abs(Hr).max()))
+    assert np.max(np.abs(W - Wr)) < tol * scale and np.max(np.abs(H - Hr)) < tol * scale
+    if d.nnz_test:
+        assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-4)
+    return W, H, csc, csr
+
+
+def test_all_empty_matrix(mfx, orc):
+    d = mfx.dataset.from_coo(7, 5, [], [], np.zeros(0, np.float32), [1], [2], np.array([3.0], np.float32))
+    W, H, csc, csr = _check(mfx, orc, d, 3)
+    assert np.all(W == 0) and np.all(H == 0)  # every row/column is empty -> exactly 0
+    Y = mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, np.ones((5, 3), np.float32), 3, 0.1)
+    assert np.all(Y == 0)
+
+
+@pytest.mark.parametrize("rows,cols,nnz", [(1, 1, 1), (1, 40, 17), (50, 1, 23), (3, 2, 5)])
+def test_tiny_shapes(mfx, orc, rows, cols, nnz):
+    rng = np.random.default_rng(rows * 100 + cols)
+    key = rng.choice(rows * cols, size=nnz, replace=False)
+    d = mfx.dataset.from_coo(rows, cols, key // cols, key % cols, rng.uniform(1, 5, nnz).astype(np.float32),
+                             [0], [0], np.array([2.5], np.float32))
+    for kw in ({}, {"panel_rows": -1}, {"panel_rows": 16}, {"schedule": 0, "kernel_variant": 0}):
+        _check(mfx, orc, d, 2, **kw)
+
+
+@pytest.mark.parametrize("k", [1, 7, 130])
+def test_rank_extremes(mfx, orc, k):
+    d = mfx.dataset.synth_ratings(300, 120, 6000, seed=k, skew=0.9, test_frac=0.02)
+    _check(mfx, orc, d, k, t=2)
+
+
+def test_no_test_set_and_T_gt_1(mfx, orc):
+    d = mfx.dataset.synth_ratings(400, 150, 9000, seed=3, skew=1.0, test_frac=0.0)
+    assert d.nnz_test == 0
+    W0 = mfx.initial_col(4, d.rows)
+    s = mfx.CcdSolver(d, None, _p(mfx, 4, 2, 3))
+    s.set_factors(W0.copy())
+    rep = s.iterate(2)
+    W, H = s.get_factors()
+    s.close()
+    assert all(r.rmse == 0.0 for r in rep)
+    Wr, Hr, *_ = orc.ccdr1(d, W0, 4, 0.05, 2, 3, 2)
+    assert np.max(np.abs(W - Wr)) < 2e-3 * np.abs(Wr).max()
+
+
+@pytest.mark.parametrize("panel_rows", [999, 1000, 1001, 65535])
+def test_panel_boundaries(mfx, orc, panel_rows):
+    """Gathered dimension exactly at / one past a panel boundary; the largest 16-bit panel."""
+    d = mfx.dataset.synth_ratings(1000, 1000, 40000, seed=9, skew=0.6, test_frac=0.01)
+    _check(mfx, orc, d, 3, panel_rows=panel_rows)
+
+
+def test_many_one_entry_segments_overflow_the_lds_rank_window(mfx, orc):
+    """Every row holds one rating: a workgroup chunk touches tens of thousands of ranks, far more
+    than the 1024-entry LDS window -> the bounds-checked kernel instantiation with its global
+    fallback must be selected and agree with the oracle."""
+    rng = np.random.default_rng(4)
+    rows, cols = 120000, 64
+    r = np.arange(rows)
+    c = rng.integers(0, cols, rows)
+    d = mfx.dataset.from_coo(rows, cols, r, c, rng.uniform(1, 5, rows).astype(np.float32),
+                             r[:100], c[:100], np.full(100, 3.0, np.float32))
+    for kw in ({"panel_rows": 0}, {"panel_rows": 32}, {"panel_rows": -1}):
+        _check(mfx, orc, d, 2, **kw)
+
+
+def test_bad_arguments_are_errors(mfx):
+    d = mfx.dataset.synth_ratings(50, 40, 500, seed=1)
+    with pytest.raises(mfx.MfxError, match="maxinneriter"):
+        mfx.CcdSolver(d, None, _p(mfx, 2, 1, 0))
+    with pytest.raises(mfx.MfxError, match="k must be"):
+        mfx.CcdSolver(d, None, _p(mfx, 0))
+    with pytest.raises(mfx.MfxError, match="wg_waves|spans_per_wg"):
+        mfx.CcdSolver(d, None, _p(mfx, 2, panel_rows=16, wg_waves=5))
+    bad = d.copy()
+    bad.csc_row_idx[0] = 10 ** 6  # index out of range must be caught on the host, not fault on the GPU
+    with pytest.raises(Exception):
+        mfx.CcdSolver(bad, None, _p(mfx, 2))
