@@ -9,10 +9,11 @@
 // Only the upper block triangle is accumulated (NT*(NT+1)/2 tiles of 16 accumulator registers).
 // fp32 MFMA is an exact k-ordered fmaf chain, so results are reproducible run to run.
 //
-// Tail (per segment, still one wave): accumulators -> LDS (row stride kp+1: conflict-free column
-// walks), + lambda on the diagonal (plain lambda, src/ALS.cpp:120-122), left-looking Cholesky in
-// the reference's own operation order (src/ALS.cpp:6-23), then L z = b and L^T y = z instead of
-// the reference's explicit inverse (same solution up to rounding; tolerance in the tests).
+// Tail (per segment, still one wave): accumulators -> LDS (lower triangle only, rows packed and
+// 16-B aligned), + lambda on the diagonal (plain lambda, src/ALS.cpp:120-122), left-looking Cholesky
+// (the reference's row-by-row scheme, src/ALS.cpp:6-23, inner dot product in four partial sums via
+// ds_read_b128), then L z = b and L^T y = z instead of the reference's explicit inverse (same
+// solution up to rounding; tolerance in the tests).
 #include "als_solver.hpp"
 
 #include <algorithm>
@@ -65,11 +66,14 @@ template <int NT>
 __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], float* lds,
                            const AlsArgs& a, uint32_t seg) {
     constexpr int KP = 32 * NT;
-    constexpr int LD = KP + 4;  // rows 16-B aligned (ds_read_b128) and 4 banks apart: 16 rows x 4 banks = conflict-free
+    // Only the lower triangle is kept, rows packed back to back with every row start rounded up to
+    // 4 floats (16-B aligned for ds_read_b128): 8.7 KB for k = 64 instead of 17.4 KB for the square,
+    // which is what lets 16 instead of 9 single-wave workgroups share a CU.
+    auto roff = [](int r) { const int g = r >> 2, m = r & 3; return 4 * (g + 1) * (2 * g + m); };
     const uint32_t lane = threadIdx.x & 63, c31 = lane & 31, h = lane >> 5;
     const int k = (int) a.k;
     float* L = lds;
-    float* bv = lds + (size_t) KP * LD;
+    float* bv = lds + roff(KP);
     {
         int ti = 0;
 #pragma unroll
@@ -81,8 +85,8 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
                     const int row = I * 32 + (r & 3) + 8 * (r >> 2) + 4 * (int) h;
                     const int col = J * 32 + (int) c31;
                     const float x = acc[ti][r];
-                    L[row * LD + col] = x;
-                    L[col * LD + row] = x;
+                    if (row >= col) L[roff(row) + col] = x;  // diagonal tiles hold both (r,c) and (c,r): same value
+                    else L[roff(col) + row] = x;
                 }
             }
         }
@@ -94,64 +98,74 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
     }
     __syncthreads();
     if (a.gram_out) {
-        for (int e = (int) lane; e < k * k; e += 64) a.gram_out[e] = L[(e / k) * LD + (e % k)];
+        for (int e = (int) lane; e < k * k; e += 64) {
+            const int r = e / k, c = e % k;
+            a.gram_out[e] = r >= c ? L[roff(r) + c] : L[roff(c) + r];
+        }
         return;
     }
-    for (int i = (int) lane; i < k; i += 64) L[i * LD + i] = add_rn(L[i * LD + i], a.lambda);
+    for (int i = (int) lane; i < k; i += 64) L[roff(i) + i] = add_rn(L[roff(i) + i], a.lambda);
     __syncthreads();
 
-    // Left-looking Cholesky on the lower triangle, row i of the reference's loop at a time:
-    //   sum = A[i][j] - sum_{q = i-1..0} L[i][q] * L[j][q];  j == i: p = sqrt(sum);  else L[j][i] = sum / p
+    // Left-looking Cholesky on the lower triangle, row i at a time (the reference's choldc1 loop,
+    // src/ALS.cpp:6-23):  sum = A[i][j] - sum_q L[i][q] * L[j][q];  j == i: p = sqrt(sum);  else
+    // L[j][i] = sum / p.  The dot product over q runs four columns per ds_read_b128 (row i is a
+    // broadcast read, row j is lane-strided and conflict-free) into four independent partial sums
+    // (the reference's single accumulator would be a 64-deep dependent chain per row); products and
+    // sums stay unfused.
     for (int i = 0; i < k; ++i) {
         float p = 0.f;
         for (int j0 = i; j0 < k; j0 += 64) {
             const int j = j0 + (int) lane;
             float sum = 0.f;
             if (j < k) {
-                sum = L[j * LD + i];
-                // reference order: q = i-1 down to 0.  Four columns per ds_read_b128 (row i is a
-                // broadcast read, row j is lane-strided and conflict-free); the subtractions stay
-                // sequential and unfused so that the factor matches src/ALS.cpp:9-12 operation for
-                // operation.
-                int q = i - 1;
-                for (; (q & 3) != 3 && q >= 0; --q) sum = sub_rn(sum, mul_rn(L[i * LD + q], L[j * LD + q]));
-                for (; q >= 3; q -= 4) {
-                    const float4 a = *reinterpret_cast<const float4*>(&L[i * LD + q - 3]);
-                    const float4 b = *reinterpret_cast<const float4*>(&L[j * LD + q - 3]);
-                    sum = sub_rn(sum, mul_rn(a.w, b.w));
-                    sum = sub_rn(sum, mul_rn(a.z, b.z));
-                    sum = sub_rn(sum, mul_rn(a.y, b.y));
-                    sum = sub_rn(sum, mul_rn(a.x, b.x));
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int q = 0;
+                for (; q + 4 <= i; q += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(&L[roff(i) + q]);
+                    const float4 y4 = *reinterpret_cast<const float4*>(&L[roff(j) + q]);
+                    s0 = add_rn(s0, mul_rn(x.x, y4.x));
+                    s1 = add_rn(s1, mul_rn(x.y, y4.y));
+                    s2 = add_rn(s2, mul_rn(x.z, y4.z));
+                    s3 = add_rn(s3, mul_rn(x.w, y4.w));
                 }
+                for (; q < i; ++q) s0 = add_rn(s0, mul_rn(L[roff(i) + q], L[roff(j) + q]));
+                sum = sub_rn(L[roff(j) + i], add_rn(add_rn(s0, s1), add_rn(s2, s3)));
             }
             if (j0 == i) {  // lane 0 holds the pivot of this row
                 const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sum)));
                 if (lane == 0 && !(piv > 0.f)) atomicAdd(a.spd_fail, 1u);
                 p = sqrtf(piv);
             }
-            if (j < k) L[j * LD + i] = (j == i) ? p : sum / p;
+            if (j < k) L[roff(j) + i] = (j == i) ? p : sum / p;
         }
         __syncthreads();
     }
-    // forward substitution L z = b (column oriented; lane r owns row r, two rows per lane for k > 64)
+    // Triangular solves (column oriented; lane r owns row r, two rows per lane for k > 64).  The
+    // pivots' reciprocals are taken once, in parallel, so that each of the 2k sequential steps is a
+    // broadcast (v_readlane, uniform index), one multiply and one fused update.
     float z0 = lane < (uint32_t) k ? bv[lane] : 0.f;
     float z1 = (NT > 2 && lane + 64 < (uint32_t) k) ? bv[lane + 64] : 0.f;
-    for (int i = 0; i < k; ++i) {
-        const float src = (NT > 2 && i >= 64) ? z1 : z0;
-        const float zi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), i & 63)) / L[i * LD + i];
+    const float rp0 = lane < (uint32_t) k ? 1.0f / L[roff((int) lane) + lane] : 0.f;
+    const float rp1 = (NT > 2 && lane + 64 < (uint32_t) k) ? 1.0f / L[roff((int) lane + 64) + lane + 64] : 0.f;
+    auto bcast = [](float x, int src_lane) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+    };
+    for (int i = 0; i < k; ++i) {  // forward: L z = b
+        const bool hi = NT > 2 && i >= 64;
+        const float zi = bcast(hi ? z1 : z0, i & 63) * bcast(hi ? rp1 : rp0, i & 63);
         if ((int) lane == i) z0 = zi;
         if (NT > 2 && (int) lane + 64 == i) z1 = zi;
-        if ((int) lane > i && (int) lane < k) z0 = sub_rn(z0, mul_rn(L[lane * LD + i], zi));
-        if (NT > 2 && (int) lane + 64 > i && (int) lane + 64 < k) z1 = sub_rn(z1, mul_rn(L[(lane + 64) * LD + i], zi));
+        if ((int) lane > i && (int) lane < k) z0 = sub_rn(z0, mul_rn(L[roff((int) lane) + i], zi));
+        if (NT > 2 && (int) lane + 64 > i && (int) lane + 64 < k) z1 = sub_rn(z1, mul_rn(L[roff((int) lane + 64) + i], zi));
     }
-    // back substitution L^T y = z
-    for (int i = k - 1; i >= 0; --i) {
-        const float src = (NT > 2 && i >= 64) ? z1 : z0;
-        const float yi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, src), i & 63)) / L[i * LD + i];
+    for (int i = k - 1; i >= 0; --i) {  // backward: L^T y = z
+        const bool hi = NT > 2 && i >= 64;
+        const float yi = bcast(hi ? z1 : z0, i & 63) * bcast(hi ? rp1 : rp0, i & 63);
         if ((int) lane == i) z0 = yi;
         if (NT > 2 && (int) lane + 64 == i) z1 = yi;
-        if ((int) lane < i) z0 = sub_rn(z0, mul_rn(L[i * LD + lane], yi));
-        if (NT > 2 && (int) lane + 64 < i) z1 = sub_rn(z1, mul_rn(L[i * LD + lane + 64], yi));
+        if ((int) lane < i) z0 = sub_rn(z0, mul_rn(L[roff(i) + lane], yi));
+        if (NT > 2 && (int) lane + 64 < i) z1 = sub_rn(z1, mul_rn(L[roff(i) + lane + 64], yi));
     }
     float* y = a.Y + (size_t) seg * k;
     if ((int) lane < k) y[lane] = z0;
@@ -265,7 +279,8 @@ __global__ __launch_bounds__(64) void k_als_reduce(AlsArgs a) {
 template <int NT>
 int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
     constexpr int KP = 32 * NT;
-    const size_t lds_bytes = ((size_t) KP * (KP + 4) + KP) * sizeof(float);
+    // packed lower triangle (rows rounded up to 4 floats) + rhs: see solve_tail
+    const size_t lds_bytes = ((size_t) 4 * (KP / 4 + 1) * (2 * (KP / 4)) + KP) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds_bytes > 48 * 1024) {
         MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_gram<NT>),
