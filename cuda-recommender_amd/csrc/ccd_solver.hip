@@ -119,6 +119,10 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     o.spans_per_wg = p.wg_waves > 0 ? (uint32_t) p.wg_waves : 16;
     o.panel_rows = 0;
     if (need_plain || p.panel_rows < 0) return o;
+    // Small matrices: a pass is a few microseconds, the operand vectors live in L1/L2, and a 56 KB
+    // slice load per workgroup would cost more than the streaming it serves (measured, ML-1M shape
+    // k = 40: 0.86 ms per outer iteration plain vs 1.57 ms with panels; ML-10M shape: panels win 1.65x).
+    if (p.panel_rows == 0 && nnz < 4000000ull) return o;
     // 64 KB of LDS per workgroup (two 1024-thread workgroups per CU): 8 KB for the staged per-segment
     // operands, 56 KB for the slice.  Measured on the Netflix shape (tools/sweep_r01_j.sh): slices of
     // 40/48/56/64/72 KB give 30.1/29.9/28.0/29.1/28.4 ms per outer iteration.
