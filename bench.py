@@ -92,7 +92,8 @@ def main() -> None:
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--tiles", type=int, default=0)
     ap.add_argument("--panel-rows", type=int, default=0, help="LDS panel size (0 auto, -1 off)")
-    ap.add_argument("--wg-waves", type=int, default=0, help="waves per workgroup of the panel kernel (0 = 8)")
+    ap.add_argument("--wg-waves", type=int, default=0, help="waves per workgroup of the panel kernel (0 = 16)")
+    ap.add_argument("--graph", type=int, default=0, help="0 = hipGraph replay of outer iterations, -1 = eager launches")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1 only: run through the sharded code path with a 1-rank RCCL communicator")
@@ -147,7 +148,7 @@ def main() -> None:
     p = mfx.parameter()
     p.k, p.lambda_, p.maxinneriter, p.device = a.k, a.lam, a.inner, local_rank
     p.schedule, p.kernel_variant, p.tiles_per_span = a.schedule, a.variant, a.tiles
-    p.panel_rows, p.wg_waves = a.panel_rows, a.wg_waves
+    p.panel_rows, p.wg_waves, p.graph = a.panel_rows, a.wg_waves, a.graph
     t0 = time.time()
     solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt if comm else None,
                            global_test_nnz=ntest_global, device_arrays=d)

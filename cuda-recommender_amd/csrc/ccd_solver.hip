@@ -209,6 +209,9 @@ int CcdSolver::create(CcdSolver** out, const mfx_csx* R, const mfx_coo* T, const
 
 CcdSolver::~CcdSolver() {
     (void) hipSetDevice(device_);
+    if (st_) (void) hipStreamSynchronize(st_);
+    if (graph_exec_) (void) hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void) hipGraphDestroy(graph_);
     for (hipEvent_t& e : ev_)
         if (e) (void) hipEventDestroy(e);
     if (st_) {
@@ -407,6 +410,42 @@ int CcdSolver::test_rmse(double* rmse_out) {
     return MFX_OK;
 }
 
+// Every launch of a fused outer iteration has the same arguments in every iteration (rank t's
+// slices and the operand packs), so after one eager iteration the whole k x 4 launch sequence is
+// captured once and replayed: one host call per outer iteration instead of 4k.  Matters when the
+// kernels are a few microseconds long (ML-100K / ML-1M sized inputs); irrelevant at Netflix size.
+int CcdSolver::enqueue_outer_iteration(int64_t oiter) {
+    const bool graphable = p_.schedule == 1 && p_.graph >= 0 && !comm_ && !prof_.enabled() && !graph_failed_;
+    if (graphable && graph_exec_) {
+        MFX_HIP(hipGraphLaunch(graph_exec_, st_));
+        pending_sub_ = (int32_t) k_ - 1;
+        return MFX_OK;
+    }
+    // first iteration runs eagerly (it also sets the kernels' LDS attributes); capture from the second
+    const bool capture = graphable && oiter >= 2;
+    if (capture && hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void) hipGetLastError();
+        graph_failed_ = true;
+        return enqueue_outer_iteration(oiter);
+    }
+    int rc = MFX_OK;
+    for (uint32_t t = 0; t < k_ && rc == MFX_OK; ++t)
+        rc = p_.schedule == 0 ? rank_as_written(t, oiter > 1) : rank_fused(t);
+    if (!capture) return rc;
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st_, &g);
+    if (rc != MFX_OK || e != hipSuccess || !g || hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0) != hipSuccess) {
+        (void) hipGetLastError();
+        if (g) (void) hipGraphDestroy(g);
+        graph_exec_ = nullptr;
+        graph_failed_ = true;  // fall back to eager launches for good
+        return enqueue_outer_iteration(oiter);
+    }
+    graph_ = g;
+    MFX_HIP(hipGraphLaunch(graph_exec_, st_));  // the capture recorded the work without running it
+    return MFX_OK;
+}
+
 int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
     MFX_REQUIRE(n_outer >= 0, "n_outer must be >= 0");
     MFX_REQUIRE(factors_set_, "mfx_ccd_iterate: call mfx_ccd_set_factors first");
@@ -416,10 +455,7 @@ int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
         double before[KernelProfiler::K_COUNT];
         for (int i = 0; i < KernelProfiler::K_COUNT; ++i) before[i] = prof_.seconds[i];
         MFX_HIP(hipEventRecord(ev_[0], st_));
-        for (uint32_t t = 0; t < k_; ++t) {
-            if (p_.schedule == 0) MFX_TRY(rank_as_written(t, oiter > 1));
-            else MFX_TRY(rank_fused(t));
-        }
+        MFX_TRY(enqueue_outer_iteration(oiter));
         MFX_HIP(hipEventRecord(ev_[1], st_));
         double rmse = 0.0;
         MFX_HIP(hipEventRecord(ev_[2], st_));

@@ -114,6 +114,10 @@ private:
     bool factors_set_ = false;
     KernelProfiler prof_;
     hipEvent_t ev_[6] = {};
+    hipGraph_t graph_ = nullptr;          // one outer iteration of the fused schedule (k ranks x 4 launches)
+    hipGraphExec_t graph_exec_ = nullptr;
+    bool graph_failed_ = false;
+    int enqueue_outer_iteration(int64_t oiter);
 };
 
 }  // namespace mfx

@@ -56,6 +56,7 @@ class parameter:
         self.tiles_per_span = 0
         self.panel_rows = 0
         self.wg_waves = 0
+        self.graph = 0
         self.log = 0  # print the reference's per-iteration "[-INFO-]" line
 
     def to_c(self) -> L.mfx_params:
@@ -65,7 +66,7 @@ class parameter:
         p.nBlocks, p.nThreadsPerBlock = int(self.nBlocks), int(self.nThreadsPerBlock)
         p.verbose, p.device, p.schedule = int(self.log), int(self.device), int(self.schedule)
         p.kernel_variant, p.profile, p.tiles_per_span = int(self.kernel_variant), int(self.profile), int(self.tiles_per_span)
-        p.panel_rows, p.wg_waves = int(self.panel_rows), int(self.wg_waves)
+        p.panel_rows, p.wg_waves, p.graph = int(self.panel_rows), int(self.wg_waves), int(self.graph)
         return p
 
 

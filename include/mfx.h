@@ -86,7 +86,10 @@ typedef struct mfx_params {
                                   LDS per workgroup when segments stay long enough), -1 = off (gather from
                                   L2), > 0 = explicit */
     int32_t wg_waves;          /* wavefronts per workgroup of the panel kernel: 4, 8 or 16; 0 = 16 */
-    int32_t reserved[2];
+    int32_t graph;             /* 0 = replay each outer iteration of the fused schedule as one hipGraph (single
+                                  GPU, no per-launch profiling): removes host launch cost when the kernels are
+                                  only a few microseconds long; -1 = always launch eagerly */
+    int32_t reserved[1];
 } mfx_params;
 
 /* One outer iteration's numbers == the fields of the reference's log line
