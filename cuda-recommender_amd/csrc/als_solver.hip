@@ -369,10 +369,11 @@ int als_half_launch(const AlsHalf& h, const float* X, float* Y, uint32_t k, floa
 }
 
 // ------------------------------------------------------------------------------------------------
-int AlsSolver::create(AlsSolver** out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space) {
+int AlsSolver::create(AlsSolver** out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space,
+                      const mfx_als_shard* shard) {
     MFX_REQUIRE(out && R && p, "mfx_als_create: null argument");
     std::unique_ptr<AlsSolver> s(new AlsSolver());
-    MFX_TRY(s->init(R, T, p, space));
+    MFX_TRY(s->init(R, T, p, space, shard));
     *out = s.release();
     return MFX_OK;
 }
@@ -387,7 +388,27 @@ AlsSolver::~AlsSolver() {
     }
 }
 
-int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space) {
+// Block boundaries of every rank, gathered through the communicator itself: each rank contributes
+// its own (lo, hi) into a zeroed vector and a sum all-reduce fills in the rest.
+static int gather_bounds(mfx_comm_s* c, int64_t lo, int64_t hi, std::vector<int64_t>* bounds, hipStream_t st) {
+    DevBuf<double> d;
+    std::vector<double> h((size_t) c->nranks * 2, 0.0);
+    h[(size_t) c->rank * 2] = (double) lo;
+    h[(size_t) c->rank * 2 + 1] = (double) hi;
+    MFX_TRY(d.alloc(h.size()));
+    MFX_TRY(d.upload(h.data(), h.size(), MFX_HOST, st));
+    MFX_TRY(comm_allreduce_f64(c, d.get(), h.size(), st));
+    MFX_HIP(hipMemcpyAsync(h.data(), d.get(), sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    bounds->assign((size_t) c->nranks + 1, 0);
+    for (int r = 0; r < c->nranks; ++r) {
+        MFX_REQUIRE((int64_t) h[(size_t) r * 2] == (*bounds)[r], "ALS shards are not contiguous in rank order");
+        (*bounds)[(size_t) r + 1] = (int64_t) h[(size_t) r * 2 + 1];
+    }
+    return MFX_OK;
+}
+
+int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space, const mfx_als_shard* shard) {
     MFX_REQUIRE(R->rows > 0 && R->cols > 0 && R->nnz >= 0, "bad matrix shape");
     MFX_REQUIRE(R->rows < (int64_t) 0xFFFFFFFFll && R->cols < (int64_t) 0xFFFFFFFFll &&
                     R->nnz < (int64_t) 0xFFFF0000ll, "matrix exceeds 32-bit index range");
@@ -399,14 +420,31 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     MFX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     for (hipEvent_t& e : ev_) MFX_HIP(hipEventCreate(&e));
     m_ = (uint32_t) R->rows; n_ = (uint32_t) R->cols; k_ = p->k;
+    uint32_t lrows = m_, lcols = n_;
+    uint64_t nnz_rows = (uint64_t) R->nnz, nnz_cols = (uint64_t) R->nnz;
+    if (shard && shard->comm) {
+        MFX_REQUIRE(space == MFX_HOST, "sharded ALS takes host pointers");
+        MFX_REQUIRE(0 <= shard->row_lo && shard->row_lo <= shard->row_hi && shard->row_hi <= R->rows &&
+                        0 <= shard->col_lo && shard->col_lo <= shard->col_hi && shard->col_hi <= R->cols,
+                    "bad ALS shard ranges");
+        comm_ = shard->comm;
+        row_lo_ = (uint32_t) shard->row_lo; col_lo_ = (uint32_t) shard->col_lo;
+        lrows = (uint32_t) (shard->row_hi - shard->row_lo); lcols = (uint32_t) (shard->col_hi - shard->col_lo);
+        nnz_rows = R->csr_row_ptr[lrows]; nnz_cols = R->csc_col_ptr[lcols];
+        global_test_nnz_ = shard->global_test_nnz;
+        MFX_TRY(gather_bounds(comm_, shard->row_lo, shard->row_hi, &row_bounds_, st_));
+        MFX_TRY(gather_bounds(comm_, shard->col_lo, shard->col_hi, &col_bounds_, st_));
+        MFX_REQUIRE(row_bounds_.back() == R->rows && col_bounds_.back() == R->cols, "ALS shards do not cover the matrix");
+    }
     // W-half walks CSR rows with csr_val (src/ALS.cpp:132), H-half walks CSC columns
-    MFX_TRY(rows_.build(m_, (uint64_t) R->nnz, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, kAlsChunk, st_));
-    MFX_TRY(cols_.build(n_, (uint64_t) R->nnz, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, kAlsChunk, st_));
+    MFX_TRY(rows_.build(lrows, nnz_rows, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, kAlsChunk, st_));
+    MFX_TRY(cols_.build(lcols, nnz_cols, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, kAlsChunk, st_));
     MFX_TRY(W_.alloc_zero((size_t) m_ * k_, st_));
     MFX_TRY(H_.alloc_zero((size_t) n_ * k_, st_));
     MFX_TRY(ws_.alloc(std::max<size_t>(1, als_ws_floats(std::max(rows_.nslots, cols_.nslots), k_))));
     MFX_TRY(spd_fail_.alloc_zero(1, st_));
     nnz_test_ = T ? T->nnz : 0;
+    if (!comm_) global_test_nnz_ = nnz_test_;
     if (nnz_test_ > 0) {
         MFX_REQUIRE(T->row && T->col && T->val, "null test array");
         MFX_TRY(t_row_.alloc(nnz_test_)); MFX_TRY(t_row_.upload(T->row, nnz_test_, space, st_));
@@ -416,6 +454,16 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     MFX_TRY(rmse_partials_.alloc_zero(kRmseBlocks, st_));
     MFX_TRY(rmse_sum_.alloc_zero(1, st_));
     MFX_HIP(hipStreamSynchronize(st_));
+    return MFX_OK;
+}
+
+// After a half-sweep every rank holds only its own block of the factor it just solved: one
+// broadcast per rank (root = owner) makes the replica whole again.
+int AlsSolver::exchange(float* X, const std::vector<int64_t>& bounds) {
+    for (int r = 0; r < comm_->nranks; ++r) {
+        const int64_t lo = bounds[r], hi = bounds[(size_t) r + 1];
+        MFX_TRY(comm_broadcast_f32(comm_, X + (size_t) lo * k_, (size_t) (hi - lo) * k_, r, st_));
+    }
     return MFX_OK;
 }
 
@@ -437,21 +485,29 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
     for (int it = 0; it < n_iter; ++it) {
         MFX_HIP(hipMemsetAsync(spd_fail_.get(), 0, sizeof(uint32_t), st_));
         MFX_HIP(hipEventRecord(ev_[0], st_));
-        MFX_TRY(als_half_launch(rows_, H_.get(), W_.get(), k_, p_.lambda, ws_.get(), spd_fail_.get(), st_));
+        MFX_TRY(als_half_launch(rows_, H_.get(), W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, ws_.get(),
+                                spd_fail_.get(), st_));
+        if (comm_) MFX_TRY(exchange(W_.get(), row_bounds_));
         MFX_HIP(hipEventRecord(ev_[1], st_));
-        MFX_TRY(als_half_launch(cols_, W_.get(), H_.get(), k_, p_.lambda, ws_.get(), spd_fail_.get(), st_));
+        MFX_TRY(als_half_launch(cols_, W_.get(), H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, ws_.get(),
+                                spd_fail_.get(), st_));
+        if (comm_) MFX_TRY(exchange(H_.get(), col_bounds_));
         MFX_HIP(hipEventRecord(ev_[2], st_));
         double rmse = 0.0, sum = 0.0;
-        if (with_rmse && nnz_test_ > 0) {
-            MFX_TRY(launch_test_sqerr(nnz_test_, t_row_.get(), t_col_.get(), t_val_.get(), W_.get(), H_.get(), m_, n_,
-                                      k_, 1, rmse_partials_.get(), kRmseBlocks, rmse_sum_.get(), st_));
+        if (with_rmse && global_test_nnz_ > 0) {
+            if (nnz_test_ > 0)
+                MFX_TRY(launch_test_sqerr(nnz_test_, t_row_.get(), t_col_.get(), t_val_.get(), W_.get(), H_.get(), m_, n_,
+                                          k_, 1, rmse_partials_.get(), kRmseBlocks, rmse_sum_.get(), st_));
+            else
+                MFX_HIP(hipMemsetAsync(rmse_sum_.get(), 0, sizeof(double), st_));
+            if (comm_) MFX_TRY(comm_allreduce_f64(comm_, rmse_sum_.get(), 1, st_));
             MFX_HIP(hipMemcpyAsync(&sum, rmse_sum_.get(), sizeof(double), hipMemcpyDeviceToHost, st_));
         }
         MFX_HIP(hipEventRecord(ev_[3], st_));
         uint32_t bad = 0;
         MFX_HIP(hipMemcpyAsync(&bad, spd_fail_.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, st_));
         MFX_HIP(hipStreamSynchronize(st_));
-        if (with_rmse && nnz_test_ > 0) rmse = std::sqrt(sum / (double) nnz_test_);
+        if (with_rmse && global_test_nnz_ > 0) rmse = std::sqrt(sum / (double) global_test_nnz_);
         float ms_w = 0.f, ms_h = 0.f, ms_r = 0.f;
         MFX_HIP(hipEventElapsedTime(&ms_w, ev_[0], ev_[1]));
         MFX_HIP(hipEventElapsedTime(&ms_h, ev_[1], ev_[2]));
@@ -466,8 +522,8 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
         ++iter_;
         if (reports) reports[it] = rep;
         // the reference prints this from inside the kernel for every failing pivot (ALS_CUDA.cu:11-13)
-        if (bad && p_.verbose) printf(" a is not positive definite! (%u pivots)\n", bad);
-        if (p_.verbose) {
+        if (bad && p_.verbose && (!comm_ || comm_->rank == 0)) printf(" a is not positive definite! (%u pivots)\n", bad);
+        if (p_.verbose && (!comm_ || comm_->rank == 0)) {
             // log line format of cuda_src/ALS_CUDA.cu:360-361
             printf("[-INFO-] iteration num %d \tupdate_time %.4lf|%.4lfs \tRMSE=%lf time:%fs\n", (int) iter_,
                    rep.update_time, update_acc_, rep.rmse, rep.rmse_time);

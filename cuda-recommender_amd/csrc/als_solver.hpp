@@ -8,6 +8,7 @@
 
 #include <vector>
 
+#include "comm.hpp"
 #include "common.hpp"
 
 namespace mfx {
@@ -36,7 +37,7 @@ struct AlsHalf {
 class AlsSolver {
 public:
     static int create(AlsSolver** out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
-                      mfx_memspace space);
+                      mfx_memspace space, const mfx_als_shard* shard = nullptr);
     ~AlsSolver();
     int set_factors(const float* W, const float* H, mfx_memspace space);
     int iterate(int n_iter, int with_rmse, mfx_iter_report* reports);
@@ -45,11 +46,17 @@ public:
 
 private:
     AlsSolver() = default;
-    int init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space);
+    int init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space, const mfx_als_shard* shard);
+    int exchange(float* X, const std::vector<int64_t>& bounds);  // every rank broadcasts its block of X
     int device_ = 0;
     hipStream_t st_ = nullptr;
     mfx_params p_{};
     uint32_t m_ = 0, n_ = 0, k_ = 0;
+    // sharded solve: this rank's row / column block and everyone's block boundaries
+    mfx_comm_s* comm_ = nullptr;
+    uint32_t row_lo_ = 0, col_lo_ = 0;
+    std::vector<int64_t> row_bounds_, col_bounds_;
+    int64_t global_test_nnz_ = 0;
     AlsHalf rows_, cols_;
     DevBuf<float> W_, H_, ws_;
     DevBuf<uint32_t> spd_fail_;

@@ -136,6 +136,15 @@ int mfx_als_create(mfx_als_t* out, const mfx_csx* R, const mfx_coo* T, const mfx
     *out = new mfx_als_s{s};
     return MFX_OK;
 }
+int mfx_als_create_sharded(mfx_als_t* out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
+                           const mfx_als_shard* shard) {
+    MFX_REQUIRE(out && shard && shard->comm, "mfx_als_create_sharded: null argument");
+    *out = nullptr;
+    AlsSolver* s = nullptr;
+    MFX_TRY(AlsSolver::create(&s, R, T, p, MFX_HOST, shard));
+    *out = new mfx_als_s{s};
+    return MFX_OK;
+}
 int mfx_als_set_factors(mfx_als_t s, const float* W, const float* H, mfx_memspace space) {
     MFX_REQUIRE(s && s->impl, "null solver");
     return s->impl->set_factors(W, H, space);

@@ -18,6 +18,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -45,6 +46,7 @@ RcclApi& api() {
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+        a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(sym("ncclBroadcast"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
     });
     return a;
@@ -205,4 +207,25 @@ int comm_allreduce_f64(mfx_comm_s* c, double* buf, size_t count, hipStream_t st)
     return MFX_OK;
 }
 
+}  // namespace mfx
+
+namespace mfx {
+int comm_broadcast_f32(mfx_comm_s* c, float* buf, size_t count, int root, hipStream_t st) {
+    if (count == 0) return MFX_OK;
+    if (c->local) {
+        LocalGroup* g = c->local;
+        const size_t bytes = count * sizeof(float);
+        MFX_HIP(hipStreamSynchronize(st));
+        if (c->rank == root) {
+            g->result.resize(bytes);
+            MFX_HIP(hipMemcpy(g->result.data(), buf, bytes, hipMemcpyDeviceToHost));
+        }
+        rendezvous(g, [] {});  // the root's data is in place
+        if (c->rank != root) MFX_HIP(hipMemcpy(buf, g->result.data(), bytes, hipMemcpyHostToDevice));
+        rendezvous(g, [] {});  // everyone has read it
+        return MFX_OK;
+    }
+    MFX_NCCL(api().Broadcast(buf, buf, count, ncclFloat32, root, static_cast<ncclComm_t>(c->nccl), st));
+    return MFX_OK;
+}
 }  // namespace mfx

@@ -23,4 +23,6 @@ int comm_destroy(mfx_comm_s* c);
 // In-place sum all-reduce on `st`.
 int comm_allreduce_f32(mfx_comm_s* c, float* buf, size_t count, hipStream_t st);
 int comm_allreduce_f64(mfx_comm_s* c, double* buf, size_t count, hipStream_t st);
+// In-place broadcast of `count` floats from rank `root`.
+int comm_broadcast_f32(mfx_comm_s* c, float* buf, size_t count, int root, hipStream_t st);
 }  // namespace mfx

@@ -45,6 +45,11 @@ class mfx_shard(C.Structure):
     _fields_ = [("comm", C.c_void_p), ("global_col_nnz", C.c_void_p), ("global_test_nnz", C.c_int64)]
 
 
+class mfx_als_shard(C.Structure):
+    _fields_ = [("comm", C.c_void_p), ("row_lo", C.c_int64), ("row_hi", C.c_int64), ("col_lo", C.c_int64),
+                ("col_hi", C.c_int64), ("global_test_nnz", C.c_int64)]
+
+
 class MfxError(RuntimeError):
     pass
 
@@ -70,6 +75,8 @@ SIGNATURES = {
     "mfx_ccd_destroy": (C.c_int, [C.c_void_p]),
     "mfx_als_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(mfx_csx), C.POINTER(mfx_coo),
                                  C.POINTER(mfx_params), C.c_int]),
+    "mfx_als_create_sharded": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(mfx_csx), C.POINTER(mfx_coo),
+                                         C.POINTER(mfx_params), C.POINTER(mfx_als_shard)]),
     "mfx_als_set_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mfx_als_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(mfx_iter_report)]),
     "mfx_als_get_factors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -386,11 +386,34 @@ class CcdSolver:
 class AlsSolver:
     """Resident ALS (mfx_als_*)."""
 
-    def __init__(self, R: RatingData, T, parameters: parameter):
+    def __init__(self, R: RatingData, T, parameters: parameter, comm: Optional[Comm] = None,
+                 row_range=None, col_range=None):
+        """With `comm`: rank-local ALS shard of the GLOBAL matrix R -- this rank solves user rows
+        row_range for the W-half and item columns col_range for the H-half (mfx_als_create_sharded)."""
         self.handle = C.c_void_p()
         self.rows, self.cols, self.k = R.rows, R.cols, int(parameters.k)
-        csx, coo, cp = _csx(R), _coo(T), parameters.to_c()
-        L.check(L.lib().mfx_als_create(C.byref(self.handle), C.byref(csx), C.byref(coo), C.byref(cp), L.MFX_HOST))
+        cp = parameters.to_c()
+        if comm is None:
+            csx, coo = _csx(R), _coo(T)
+            L.check(L.lib().mfx_als_create(C.byref(self.handle), C.byref(csx), C.byref(coo), C.byref(cp), L.MFX_HOST))
+            return
+        (rl, rh), (cl, ch) = row_range, col_range
+        a, b = int(R.csr_row_ptr[rl]), int(R.csr_row_ptr[rh])
+        c, d = int(R.csc_col_ptr[cl]), int(R.csc_col_ptr[ch])
+        keep = [np.ascontiguousarray(x) for x in (
+            (R.csr_row_ptr[rl:rh + 1] - np.uint32(a)).astype(np.uint32), R.csr_col_idx[a:b], R.csr_val[a:b],
+            (R.csc_col_ptr[cl:ch + 1] - np.uint32(c)).astype(np.uint32), R.csc_row_idx[c:d], R.csc_val[c:d])]
+        self._keep = keep
+        csx = L.mfx_csx(R.rows, R.cols, 0, _vp(keep[3]), _vp(keep[4]), _vp(keep[5]), _vp(keep[0]), _vp(keep[1]), _vp(keep[2]))
+        csx.csc_col_ptr = keep[3].ctypes.data_as(C.c_void_p)  # pointer arrays are never empty
+        csx.csr_row_ptr = keep[0].ctypes.data_as(C.c_void_p)
+        sel = (R.test_row >= rl) & (R.test_row < rh)
+        Tl = TestData(R.rows, R.cols, np.ascontiguousarray(R.test_row[sel]), np.ascontiguousarray(R.test_col[sel]),
+                      np.ascontiguousarray(R.test_val[sel]))
+        self._keep.append(Tl)
+        coo = _coo(Tl)
+        shard = L.mfx_als_shard(comm.handle, rl, rh, cl, ch, int(R.test_val.shape[0]))
+        L.check(L.lib().mfx_als_create_sharded(C.byref(self.handle), C.byref(csx), C.byref(coo), C.byref(cp), C.byref(shard)))
 
     def set_factors(self, H, W=None):
         _f32c(H, (self.cols, self.k))
@@ -477,6 +500,13 @@ def als_half(ptr, idx, val, X, k: int, lam: float, device: int = 0) -> np.ndarra
 def partition_rows(R: RatingData, nshards: int) -> np.ndarray:
     bounds = np.zeros(nshards + 1, np.int64)
     L.check(L.lib().mfx_partition_rows(R.rows, _u32(R.csr_row_ptr), nshards, bounds.ctypes.data_as(L.i64p)))
+    return bounds
+
+
+def partition_cols(R: RatingData, nshards: int) -> np.ndarray:
+    """nnz-balanced contiguous column blocks (the H-half of a sharded ALS)."""
+    bounds = np.zeros(nshards + 1, np.int64)
+    L.check(L.lib().mfx_partition_rows(R.cols, _u32(R.csc_col_ptr), nshards, bounds.ctypes.data_as(L.i64p)))
     return bounds
 
 

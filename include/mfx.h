@@ -161,6 +161,20 @@ int mfx_ccd_destroy(mfx_ccd_t s);
 
 int mfx_als_create(mfx_als_t* out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
                    mfx_memspace space);
+/* Multi-GPU ALS (SURVEY.md 8e "ALS", 8f N4): rank g owns user rows [row_lo,row_hi) for the W-half
+ * and item columns [col_lo,col_hi) for the H-half; W and H are replicated and every half ends with
+ * one broadcast per rank of its freshly solved block.  R->rows / R->cols are the GLOBAL sizes;
+ * csr_* describe the local rows (row_ptr rebased to 0, GLOBAL column indices), csc_* the local
+ * columns (col_ptr rebased to 0, GLOBAL row indices); R->nnz is ignored (each orientation's count
+ * is the last entry of its pointer array).  T holds the test ratings of the local rows with GLOBAL
+ * indices.  Host pointers only. */
+typedef struct mfx_als_shard {
+    mfx_comm_t comm;
+    int64_t row_lo, row_hi, col_lo, col_hi;
+    int64_t global_test_nnz;
+} mfx_als_shard;
+int mfx_als_create_sharded(mfx_als_t* out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
+                           const mfx_als_shard* shard);
 int mfx_als_set_factors(mfx_als_t s, const float* W, const float* H, mfx_memspace space);
 int mfx_als_iterate(mfx_als_t s, int n_iter, int with_rmse, mfx_iter_report* reports);
 int mfx_als_get_factors(mfx_als_t s, float* W, float* H, mfx_memspace space);

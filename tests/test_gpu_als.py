@@ -105,3 +105,40 @@ def test_als_rank_limit_is_an_error(mfx):
     d = mfx.dataset.synth_ratings(100, 80, 1000, seed=2)
     with pytest.raises(mfx.MfxError, match="not supported"):
         mfx.AlsSolver(d, None, _p(mfx, 129, 0.1, 1))
+
+
+@pytest.mark.parametrize("nranks,k", [(2, 16), (3, 40)])
+def test_sharded_als_multi_rank_loopback(mfx, orc, nranks, k):
+    """Multi-GPU ALS: rank g solves its user rows in the W-half and its item columns
+    in the H-half, each half ends with one broadcast per rank.  Ranks = threads of this process on
+    one GPU (loopback communicator); result must match the unsharded oracle AND the unsharded GPU solve."""
+    import threading
+    d = mfx.dataset.synth_ratings(2500, 700, 90_000, seed=77, skew=1.0, test_frac=0.02, empty_row_frac=0.02)
+    H0 = mfx.initial_col(d.cols, k)
+    Wr, Hr, rmse_ref, _ = orc.als(d, H0, k, 0.05, 2, orc.max_threads())
+    s = mfx.AlsSolver(d, mfx.test_data_of(d), _p(mfx, k, 0.05, 2))
+    s.set_factors(H0.copy()); s.iterate(2); W1, H1 = s.get_factors(); s.close()
+    rb, cb = mfx.partition_rows(d, nranks), mfx.partition_cols(d, nranks)
+    out, errs = [None] * nranks, []
+
+    def run(r):
+        try:
+            comm = mfx.Comm(None, r, nranks, 0, local_group=7000 + nranks)
+            sv = mfx.AlsSolver(d, None, _p(mfx, k, 0.05, 2), comm=comm,
+                               row_range=(int(rb[r]), int(rb[r + 1])), col_range=(int(cb[r]), int(cb[r + 1])))
+            sv.set_factors(H0.copy())
+            rep = sv.iterate(2)
+            out[r] = (sv.get_factors(), [x.rmse for x in rep])
+            sv.close(); comm.close()
+        except Exception as e:
+            errs.append(e)
+            raise
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not errs and all(o is not None for o in out), errs
+    for (W, H), rm in out:
+        assert np.array_equal(W.view(np.uint32), W1.view(np.uint32)) and np.array_equal(H.view(np.uint32), H1.view(np.uint32))
+        assert np.all(np.abs(np.array(rm) - rmse_ref) < 1e-4)
+        assert relerr(W, Wr) < 5e-3 and relerr(H, Hr) < 5e-3

@@ -37,3 +37,20 @@ def test_mfx_train_matches_reference_log(tmp_path, solver):
         assert (m, n) == (d.rows, k)
         W = W.T
     assert np.max(np.abs(W - ref)) < 5e-3 * np.max(np.abs(ref))
+
+
+def test_sweep_harness_protocol(tmp_path):
+    """tools/sweep_times.py: the K x T x repeats protocol of the reference's scripts/times.sh, JSON lines out."""
+    import json
+    import sys
+    out = tmp_path / "res.jsonl"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_times.py"), "synth:300x200x6000", "--out", str(out),
+                        "--iters", "2", "--repeats", "2", "--ks", "1", "5", "--ts", "1", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = [json.loads(l) for l in open(out)]
+    assert len(rows) == 2 * 2 * 2 and all(x["status"] == 0 and len(x["rmse"]) == 2 for x in rows)
+    assert {(x["k"], x["T"]) for x in rows} == {(1, 1), (1, 3), (5, 1), (5, 3)}
+    # repeats of one configuration are bitwise reproducible
+    a, b = [x for x in rows if (x["k"], x["T"]) == (5, 3)]
+    assert a["rmse"] == b["rmse"] and a["nnz_per_s_per_iter"] > 0
