@@ -12,6 +12,7 @@
 
 static void runCUDA(SparseMatrix& R, TestData& T, MatData& W, MatData& H, parameter& parameters, bool ALS) {
     if (ALS) kernel_wrapper_als_NV(R, T, W, H, parameters);
+    else if (parameters.n_gpus > 1) kernel_wrapper_ccdpp_multi(R, T, W, H, parameters, parameters.n_gpus);
     else kernel_wrapper_ccdpp_NV(R, T, W, H, parameters);
 }
 

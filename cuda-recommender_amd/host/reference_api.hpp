@@ -71,3 +71,72 @@ inline void kernel_wrapper_als_NV(SparseMatrix& R, TestData& T, MatData& W, MatD
     mfx_shim::unflatten(w, W);
     mfx_shim::unflatten(h, H);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU CCD++ from one process: one host thread per shard, each driving its own device and its
+// own resident solver; shards are nnz-balanced user-row blocks (mfx_partition_rows /
+// mfx_extract_shard) and exchange one all-reduce of the (g, h) column partials per inner iteration.
+// With fewer devices than shards the shards share device 0 through the in-process loopback
+// communicator (a rehearsal mode: correct, not fast).  Same in/out contract as the 1-GPU wrapper.
+// ---------------------------------------------------------------------------------------------
+#include <thread>
+
+inline void kernel_wrapper_ccdpp_multi(SparseMatrix& R, TestData& T, MatData& W, MatData& H, parameter& parameters,
+                                       int n_shards) {
+    const mfx_csx r = mfx_shim::view(R);
+    const int ndev = mfx_device_count();
+    const bool loopback = ndev < n_shards;
+    if (ndev < 1) { fprintf(stderr, "CCD FAILED: no usable HIP device\n"); return; }
+    std::vector<int64_t> bounds((size_t) n_shards + 1);
+    mfx_partition_rows(r.rows, r.csr_row_ptr, n_shards, bounds.data());
+    std::vector<uint32_t> col_nnz((size_t) r.cols);
+    for (int64_t c = 0; c < r.cols; ++c) col_nnz[c] = r.csc_col_ptr[c + 1] - r.csc_col_ptr[c];
+    unsigned char uid[MFX_COMM_ID_BYTES];
+    if (!loopback && mfx_comm_unique_id(uid) != MFX_OK) { fprintf(stderr, "CCD FAILED: %s\n", mfx_last_error()); return; }
+    if (loopback) printf("[info] %d shards on %d device(s): loopback communicator (rehearsal mode)\n", n_shards, ndev);
+    const unsigned k = parameters.k;
+    std::vector<std::vector<float>> Wl(n_shards), Hl(n_shards);
+    std::vector<int> status(n_shards, MFX_OK);
+    std::vector<std::string> errors(n_shards);
+    auto worker = [&](int g) {
+        const int64_t lo = bounds[g], hi = bounds[g + 1], nr = hi - lo;
+        const uint32_t lnnz = r.csr_row_ptr[hi] - r.csr_row_ptr[lo];
+        std::vector<uint32_t> rp(nr + 1), ci(lnnz), cp(r.cols + 1), ri(lnnz);
+        std::vector<float> rv(lnnz), cv(lnnz);
+        int rc = mfx_extract_shard(&r, lo, hi, rp.data(), ci.data(), rv.data(), cp.data(), ri.data(), cv.data());
+        std::vector<uint32_t> tr, tc;
+        std::vector<float> tv;
+        for (long q = 0; q < T.nnz; ++q)
+            if (T.getTestRow()[q] >= lo && T.getTestRow()[q] < hi) {
+                tr.push_back(T.getTestRow()[q] - (uint32_t) lo); tc.push_back(T.getTestCol()[q]); tv.push_back(T.getTestVal()[q]);
+            }
+        mfx_csx lr = {nr, r.cols, (int64_t) lnnz, cp.data(), ri.data(), cv.data(), rp.data(), ci.data(), rv.data()};
+        mfx_coo lt = {(int64_t) tv.size(), tr.data(), tc.data(), tv.data()};
+        mfx_params p = mfx_shim::params_of(parameters);
+        p.device = loopback ? 0 : g;
+        mfx_comm_t comm = nullptr;
+        mfx_ccd_t s = nullptr;
+        if (rc == MFX_OK) rc = loopback ? mfx_comm_create_local(&comm, 4242, g, n_shards, 0) : mfx_comm_create(&comm, uid, g, n_shards, g);
+        mfx_shard sh = {comm, col_nnz.data(), (int64_t) T.nnz};
+        if (rc == MFX_OK) rc = mfx_ccd_create(&s, &lr, &lt, &p, MFX_HOST, &sh);
+        Wl[g].resize((size_t) k * nr); Hl[g].resize((size_t) k * r.cols);
+        for (unsigned t = 0; t < k; ++t) for (int64_t i = 0; i < nr; ++i) Wl[g][(size_t) t * nr + i] = W[t][lo + i];
+        if (rc == MFX_OK) rc = mfx_ccd_set_factors(s, Wl[g].data(), nullptr, MFX_HOST);
+        if (rc == MFX_OK) rc = mfx_ccd_iterate(s, parameters.maxiter, 1, nullptr);
+        if (rc == MFX_OK) rc = mfx_ccd_get_factors(s, Wl[g].data(), Hl[g].data(), MFX_HOST);
+        if (rc != MFX_OK) errors[g] = mfx_last_error();
+        mfx_ccd_destroy(s);
+        mfx_comm_destroy(comm);
+        status[g] = rc;
+    };
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_shards; ++g) th.emplace_back(worker, g);
+    for (auto& x : th) x.join();
+    for (int g = 0; g < n_shards; ++g)
+        if (status[g] != MFX_OK) { fprintf(stderr, "CCD FAILED: shard %d: %s\n", g, errors[g].c_str()); return; }
+    for (int g = 0; g < n_shards; ++g) {
+        const int64_t lo = bounds[g], nr = bounds[g + 1] - lo;
+        for (unsigned t = 0; t < k; ++t) for (int64_t i = 0; i < nr; ++i) W[t][lo + i] = Wl[g][(size_t) t * nr + i];
+    }
+    for (unsigned t = 0; t < k; ++t) for (int64_t j = 0; j < r.cols; ++j) H[t][j] = Hl[0][(size_t) t * r.cols + j];  // replicas agree
+}

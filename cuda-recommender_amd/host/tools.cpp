@@ -162,6 +162,7 @@ void exit_with_help() {
            "    -device id : HIP device ordinal (default 0)\n"
            "    -schedule s : 1 fused passes (default), 0 one launch per reference kernel\n"
            "    -panel rows : LDS panel size, 0 auto, -1 off\n"
+           "    -nGPUs n : CCD++ over n user-row-block shards, one GPU each (RCCL all-reduce per inner iteration)\n"
            "    -save file : write W then H in the reference's model format (save_mat_t)\n");
     exit(EXIT_FAILURE);
 }
@@ -178,6 +179,7 @@ parameter parse_command_line(int argc, char** argv) {
         else if (!strcmp(flag, "-device")) param.device = atoi(argv[i]);
         else if (!strcmp(flag, "-schedule")) param.schedule = atoi(argv[i]);
         else if (!strcmp(flag, "-panel")) param.panel_rows = atoi(argv[i]);
+        else if (!strcmp(flag, "-nGPUs")) param.n_gpus = atoi(argv[i]);
         else if (!strcmp(flag, "-save")) { /* handled by main (it rescans argv) */ }
         else if (!strcmp(flag, "-CUDA") || !strcmp(flag, "-HIP")) { param.enable_cuda = true; --i; }  // valueless: give it back
         else if (!strcmp(flag, "-OMP")) { param.enable_omp = true; --i; }

@@ -54,3 +54,22 @@ def test_sweep_harness_protocol(tmp_path):
     # repeats of one configuration are bitwise reproducible
     a, b = [x for x in rows if (x["k"], x["T"]) == (5, 3)]
     assert a["rmse"] == b["rmse"] and a["nnz_per_s_per_iter"] > 0
+
+
+def test_mfx_train_multi_shard(tmp_path):
+    """mfx_train -nGPUs 3: three user-row-block shards from one process (loopback communicator on a
+    1-GPU box, RCCL when three devices exist); log and model must match the reference like the 1-GPU run."""
+    import mfx
+    g, d = load_golden("small")
+    mfx.dataset.write_dataset_dir(str(tmp_path / "ds"), d)
+    exe = os.path.join(ROOT, "cuda-recommender_amd", "mfx_train")
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    r = subprocess.run([exe, "-CUDA", "-nGPUs", "3", "-k", str(k), "-l", repr(lam), "-t", "3", "-T", "1",
+                        "-save", str(tmp_path / "model.bin"), str(tmp_path / "ds")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CCD FAILED" not in r.stderr, r.stderr
+    rmse = np.array([float(x) for x in re.findall(r"\[-INFO-\] iteration num \d+ .*RMSE=([0-9.]+)", r.stdout)])
+    assert rmse.shape == (3,) and np.all(np.abs(rmse - g["ccd_T1__rmse"]) < 1e-4), (rmse, r.stdout)
+    raw = open(tmp_path / "model.bin", "rb").read()
+    m, n = struct.unpack("<qq", raw[:16])
+    W = np.frombuffer(raw[16:16 + 4 * m * n], np.float32).reshape(m, n).T
+    assert np.max(np.abs(W - g["ccd_T1__W"])) < 2e-3 * np.max(np.abs(g["ccd_T1__W"]))
