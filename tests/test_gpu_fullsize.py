@@ -85,3 +85,43 @@ def test_fullsize_as_written_schedule_agrees(big):
     s0.close()
     assert abs(rep0[0].rmse - rep1[0].rmse) < 1e-5
     assert np.max(np.abs(W0 - W1)) < 1e-3 * np.max(np.abs(W1)) and np.max(np.abs(H0 - H1)) < 1e-3 * np.max(np.abs(H1))
+
+
+def test_fullsize_als_normal_equations(big):
+    """BASELINE configs[3] (Netflix shape, k = 64, ALS): after one iteration every sampled row of W and
+    column of H must satisfy its normal equations (X_Omega^T X_Omega + lambda I) y = X_Omega^T r, checked
+    against an independent fp64 solve; RMSE must fall between iterations.  (H-half is checked against
+    the W it was computed from, i.e. the returned W; the W-half against the H of the previous
+    iteration, so the row check runs on a 1-iteration solve.)"""
+    mfx, torch, d = big
+    from mfx import synth_torch
+    host = synth_torch.to_rating_data(d)
+    p = mfx.parameter(); p.k, p.lambda_ = K, 0.05
+    H0 = mfx.initial_col(COLS, K)
+    s = mfx.AlsSolver(host, mfx.test_data_of(host), p)
+    s.set_factors(H0.copy())
+    rep = s.iterate(1)
+    W, H = s.get_factors()
+    rep2 = s.iterate(1)
+    s.close()
+    assert rep2[0].rmse < rep[0].rmse < 1.5
+    rng = np.random.default_rng(0)
+    lam = 0.05
+
+    def check(ptr, idx, val, X, Y, picks):
+        worst = 0.0
+        for c in picks:
+            lo, hi = int(ptr[c]), int(ptr[c + 1])
+            if hi == lo:
+                assert np.all(Y[c] == 0)
+                continue
+            Xo = X[idx[lo:hi].astype(np.int64)].astype(np.float64)
+            A = Xo.T @ Xo + lam * np.eye(K)
+            y = np.linalg.solve(A, Xo.T @ val[lo:hi].astype(np.float64))
+            worst = max(worst, float(np.max(np.abs(Y[c] - y)) / max(1e-12, np.max(np.abs(y)))))
+        return worst
+
+    rows = rng.choice(ROWS, 400, replace=False)
+    cols = np.concatenate([rng.choice(COLS, 150, replace=False), [int(np.argmax(np.diff(host.csc_col_ptr.astype(np.int64))))]])
+    assert check(host.csr_row_ptr, host.csr_col_idx, host.csr_val, H0, W, rows) < 2e-3      # W solved against H0
+    assert check(host.csc_col_ptr, host.csc_row_idx, host.csc_val, W, H, cols) < 2e-3       # H solved against that W
