@@ -10,6 +10,7 @@
 //   * mfx_params.schedule = 0 runs the kernel sequence exactly as written, for A/B and parity.
 #include "ccd_solver.hpp"
 
+#include <atomic>
 #include <cmath>
 
 namespace mfx {
@@ -40,8 +41,18 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_REQUIRE(ptr_h[0] == 0 && ptr_h[nseg] == nnz, "segment pointer array does not span [0, nnz]");
     for (uint32_t c = 0; c < nseg; ++c)
         MFX_REQUIRE(ptr_h[c] <= ptr_h[c + 1], "segment pointer array is not monotone at %u", c);
-    for (uint64_t q = 0; q < nnz; ++q)
-        MFX_REQUIRE(idx_h[q] < G, "index %u at position %llu is out of range [0, %u)", idx_h[q], (unsigned long long) q, G);
+    {   // every gathered index must be in range: checked here, on the host, so that a bad input is an
+        // error message and not a GPU fault
+        struct Ctx { const uint32_t* idx; uint32_t G; std::atomic<uint64_t> bad; } cx{idx_h, G, {~0ull}};
+        parallel_ranges_u64(nnz, [](uint64_t b, uint64_t e, void* p) {
+            Ctx& c = *static_cast<Ctx*>(p);
+            for (uint64_t q = b; q < e; ++q)
+                if (c.idx[q] >= c.G) { uint64_t cur = c.bad.load(); while (q < cur && !c.bad.compare_exchange_weak(cur, q)) {} break; }
+        }, &cx);
+        const uint64_t bad = cx.bad.load();
+        MFX_REQUIRE(bad == ~0ull, "index %u at position %llu is out of range [0, %u)", idx_h[bad == ~0ull ? 0 : bad],
+                    (unsigned long long) bad, G);
+    }
     if (opt.panel_rows) {
         MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16,
                     "wg_waves must be 4, 8 or 16");
@@ -51,9 +62,14 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_REQUIRE(L.padded_nnz < 0xFFFFFF00ull, "padded non-zero count exceeds the 32-bit position range");
 
     std::vector<float> val_st(L.padded_nnz, 0.f);
-    if (val_h)
-        for (uint64_t e = 0; e < L.padded_nnz; ++e)
-            if (L.perm[e] != ~0u) val_st[e] = val_h[L.perm[e]];
+    if (val_h) {
+        struct Ctx { float* dst; const float* src; const uint32_t* perm; } cx{val_st.data(), val_h, L.perm.data()};
+        parallel_ranges_u64(L.padded_nnz, [](uint64_t b, uint64_t e, void* p) {
+            Ctx& c = *static_cast<Ctx*>(p);
+            for (uint64_t i = b; i < e; ++i)
+                if (c.perm[i] != ~0u) c.dst[i] = c.src[c.perm[i]];
+        }, &cx);
+    }
 
     const size_t nv = (size_t) L.npanels * nseg;
     MFX_TRY(ptr_.alloc((size_t) nseg + 1));
@@ -66,7 +82,11 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     if (L.panel_rows) {  // panel-local indices (and the zero slot, index panel_rows) fit 16 bits
         MFX_REQUIRE(L.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
         idx16.resize(L.padded_nnz);
-        for (uint64_t e = 0; e < L.padded_nnz; ++e) idx16[e] = (uint16_t) L.idx_local[e];
+        struct Ctx { uint16_t* dst; const uint32_t* src; } cx{idx16.data(), L.idx_local.data()};
+        parallel_ranges_u64(L.padded_nnz, [](uint64_t b, uint64_t e, void* p) {
+            Ctx& c = *static_cast<Ctx*>(p);
+            for (uint64_t i = b; i < e; ++i) c.dst[i] = (uint16_t) c.src[i];
+        }, &cx);
         MFX_TRY(idx16_.alloc(L.padded_nnz));
         MFX_TRY(idx16_.upload(idx16.data(), L.padded_nnz, MFX_HOST, st));
     } else {

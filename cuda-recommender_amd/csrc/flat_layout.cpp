@@ -35,6 +35,18 @@ void parallel_ranges(uint32_t n, F fn) {
 
 }  // namespace
 
+void parallel_ranges_u64(uint64_t n, void (*fn)(uint64_t, uint64_t, void*), void* ctx) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    if (n < (1u << 16) || nt == 1) { fn(0, n, ctx); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) {
+        const uint64_t b = n * t / nt, e = n * (t + 1) / nt;
+        th.emplace_back([=] { fn(b, e, ctx); });
+    }
+    for (auto& x : th) x.join();
+}
+
 void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, uint64_t nnz, uint32_t G,
                        const FlatLayoutOptions& opt, FlatLayoutHost* out) {
     FlatLayoutHost& L = *out;

@@ -70,6 +70,10 @@ struct FlatLayoutOptions {
 };
 
 // ptr/idx are the input orientation (host pointers); G is the gathered dimension.
+// Runs fn(begin, end) over [0, n) on up to 16 host threads (plain std::thread: libmfx must not drag a
+// second OpenMP runtime into a process that already hosts torch's).
+void parallel_ranges_u64(uint64_t n, void (*fn)(uint64_t, uint64_t, void*), void* ctx);
+
 void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, uint64_t nnz, uint32_t G,
                        const FlatLayoutOptions& opt, FlatLayoutHost* out);
 
