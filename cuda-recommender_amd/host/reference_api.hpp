@@ -8,7 +8,12 @@
 #include <vector>
 
 #include "mfx.h"
+// Inside the reference's own tree define MFX_SHIM_EXTERNAL_TYPES and include its "pmf.h" first: the
+// shim then uses the reference's SparseMatrix / TestData / MatData / parameter as they are
+// (tests/test_host.py::test_shim_compiles_against_reference_headers does exactly that).
+#ifndef MFX_SHIM_EXTERNAL_TYPES
 #include "pmf.hpp"
+#endif
 
 namespace mfx_shim {
 
@@ -30,7 +35,9 @@ inline mfx_params params_of(const parameter& p) {
     q.k = p.k; q.lambda = p.lambda; q.maxiter = p.maxiter; q.maxinneriter = p.maxinneriter;
     q.nBlocks = p.nBlocks; q.nThreadsPerBlock = p.nThreadsPerBlock;
     q.verbose = 1;  // the reference wrappers always print the per-iteration line
+#ifndef MFX_SHIM_EXTERNAL_TYPES  // knobs only this repository's `parameter` has
     q.device = p.device; q.schedule = p.schedule; q.kernel_variant = p.kernel_variant; q.panel_rows = p.panel_rows;
+#endif
     return q;
 }
 // MatData (vector of vectors) <-> the flat layouts of mfx.h; 64-bit indexing (the reference's

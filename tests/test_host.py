@@ -202,3 +202,28 @@ def test_cli_predict_from_model_file(mfx, tmp_path):
     assert np.allclose(pred, want, atol=1e-5)
     rmse = float(np.sqrt(np.mean((want - np.array([v for *_, v in trip])) ** 2)))
     assert f"[FINAL INFO] Test RMSE = {rmse:f}" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/pmf.h"), reason="the reference tree only exists in the build container")
+def test_shim_compiles_against_reference_headers(tmp_path):
+    """Drop-in proof: host/reference_api.hpp (both kernel_wrapper_*_NV signatures + the multi-shard
+    wrapper) compiles against the REFERENCE's own pmf.h types and links with libmfx.so, with a
+    main() that calls them exactly like src/main.cpp:11-17 does."""
+    import subprocess
+    tu = tmp_path / "dropin.cpp"
+    tu.write_text('''
+#include "pmf.h"            // the reference's SparseMatrix / TestData / MatData / parameter
+#define MFX_SHIM_EXTERNAL_TYPES
+#include "reference_api.hpp"
+void runCUDA(SparseMatrix& R, TestData& T, MatData& W, MatData& H, parameter& parameters, bool ALS) {
+    if (ALS) kernel_wrapper_als_NV(R, T, W, H, parameters);
+    else kernel_wrapper_ccdpp_NV(R, T, W, H, parameters);
+}
+int main() { return 0; }
+''')
+    pkg = os.path.join(ROOT, "cuda-recommender_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-fopenmp", "-pthread", "-w", "-I/root/reference/src", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(pkg, "host"), str(tu), "-L" + pkg, "-lmfx", "-Wl,-rpath," + pkg,
+                        "-o", str(tmp_path / "dropin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([str(tmp_path / "dropin")]).returncode == 0
