@@ -7,7 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst, tag = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles"), sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(dst, exist_ok=True)
 rows = []
-for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+# gpurun merges into gpurun_out/ without deleting older runs: keep only the newest file per pass
+def newest(dirname, pattern):
+    fs = glob.glob(os.path.join(src, dirname, "**", pattern), recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+for f in newest("stats", "*kernel_stats.csv"):
     rd = list(csv.reader(open(f)))
     rows = [rd[0]] + [r for r in rd[1:] if "mfx" in r[0]]
 csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w")).writerows(rows)
@@ -25,7 +29,7 @@ bench = json.loads(line)
 Z = int(bench["config"]["nnz_global"])
 def mean(dirname, kern, ctr):
     s = n = 0
-    for f in glob.glob(os.path.join(src, dirname, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(dirname, "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr:
                 s += float(r["Counter_Value"]); n += 1
