@@ -109,37 +109,82 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
 
     // Left-looking Cholesky on the lower triangle, row i at a time (the reference's choldc1 loop,
     // src/ALS.cpp:6-23):  sum = A[i][j] - sum_q L[i][q] * L[j][q];  j == i: p = sqrt(sum);  else
-    // L[j][i] = sum / p.  The dot product over q runs four columns per ds_read_b128 (row i is a
-    // broadcast read, row j is lane-strided and conflict-free) into four independent partial sums
-    // (the reference's single accumulator would be a 64-deep dependent chain per row); products and
-    // sums stay unfused.
-    for (int i = 0; i < k; ++i) {
-        float p = 0.f;
-        for (int j0 = i; j0 < k; j0 += 64) {
-            const int j = j0 + (int) lane;
-            float sum = 0.f;
-            if (j < k) {
+    // L[j][i] = sum / p.  The dot product over q runs in four independent partial sums (the
+    // reference's single accumulator would be a 64-deep dependent chain per row); products and sums
+    // stay unfused.  Same arithmetic in both variants below, so they agree bit for bit.
+    if constexpr (NT <= 2) {
+        // k <= 64: lane j keeps row j in registers.  Row i reaches the other lanes through
+        // v_readlane (static register, static lane after full unrolling), so the factorisation
+        // reads no LDS at all -- the LDS form below moves ~1 MB through the LDS pipe per system and
+        // was what bounded the user half-sweep (480 k systems).
+        float r[KP];
+        const int row = (int) lane < KP ? (int) lane : KP - 1;  // KP = 32: the upper half-wave mirrors row 31, never stores
+#pragma unroll
+        for (int q = 0; q < KP; q += 4) {  // reads past the end of a short row stay inside L; those slots are never used
+            const float4 x = *reinterpret_cast<const float4*>(&L[roff(row) + q]);
+            r[q] = x.x; r[q + 1] = x.y; r[q + 2] = x.z; r[q + 3] = x.w;
+        }
+        auto rl = [](float x, int src_lane) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+        };
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            if (i < k) {  // wave-uniform
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                int q = 0;
-                for (; q + 4 <= i; q += 4) {
-                    const float4 x = *reinterpret_cast<const float4*>(&L[roff(i) + q]);
-                    const float4 y4 = *reinterpret_cast<const float4*>(&L[roff(j) + q]);
-                    s0 = add_rn(s0, mul_rn(x.x, y4.x));
-                    s1 = add_rn(s1, mul_rn(x.y, y4.y));
-                    s2 = add_rn(s2, mul_rn(x.z, y4.z));
-                    s3 = add_rn(s3, mul_rn(x.w, y4.w));
+#pragma unroll
+                for (int q = 0; q + 4 <= i; q += 4) {
+                    s0 = add_rn(s0, mul_rn(rl(r[q], i), r[q]));
+                    s1 = add_rn(s1, mul_rn(rl(r[q + 1], i), r[q + 1]));
+                    s2 = add_rn(s2, mul_rn(rl(r[q + 2], i), r[q + 2]));
+                    s3 = add_rn(s3, mul_rn(rl(r[q + 3], i), r[q + 3]));
                 }
-                for (; q < i; ++q) s0 = add_rn(s0, mul_rn(L[roff(i) + q], L[roff(j) + q]));
-                sum = sub_rn(L[roff(j) + i], add_rn(add_rn(s0, s1), add_rn(s2, s3)));
-            }
-            if (j0 == i) {  // lane 0 holds the pivot of this row
-                const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sum)));
+#pragma unroll
+                for (int q = i & ~3; q < i; ++q) s0 = add_rn(s0, mul_rn(rl(r[q], i), r[q]));
+                const float sum = sub_rn(r[i], add_rn(add_rn(s0, s1), add_rn(s2, s3)));
+                const float piv = rl(sum, i);
                 if (lane == 0 && !(piv > 0.f)) atomicAdd(a.spd_fail, 1u);
-                p = sqrtf(piv);
+                const float p = sqrtf(piv);
+                r[i] = (int) lane == i ? p : sum / p;  // lanes j < i write a slot (column i > j) they never read
             }
-            if (j < k) L[roff(j) + i] = (j == i) ? p : sum / p;
+        }
+        if ((int) lane < KP) {
+#pragma unroll
+            for (int q = 0; q < KP; q += 4)
+                if (q <= (int) lane)  // row j owns roundup4(j + 1) floats
+                    *reinterpret_cast<float4*>(&L[roff((int) lane) + q]) = make_float4(r[q], r[q + 1], r[q + 2], r[q + 3]);
         }
         __syncthreads();
+    } else {
+        // k > 64: rows do not fit the register file next to the accumulators; row i is a broadcast
+        // ds_read_b128, row j lane-strided and conflict-free.
+        for (int i = 0; i < k; ++i) {
+            float p = 0.f;
+            for (int j0 = i; j0 < k; j0 += 64) {
+                const int j = j0 + (int) lane;
+                float sum = 0.f;
+                if (j < k) {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                    int q = 0;
+                    for (; q + 4 <= i; q += 4) {
+                        const float4 x = *reinterpret_cast<const float4*>(&L[roff(i) + q]);
+                        const float4 y4 = *reinterpret_cast<const float4*>(&L[roff(j) + q]);
+                        s0 = add_rn(s0, mul_rn(x.x, y4.x));
+                        s1 = add_rn(s1, mul_rn(x.y, y4.y));
+                        s2 = add_rn(s2, mul_rn(x.z, y4.z));
+                        s3 = add_rn(s3, mul_rn(x.w, y4.w));
+                    }
+                    for (; q < i; ++q) s0 = add_rn(s0, mul_rn(L[roff(i) + q], L[roff(j) + q]));
+                    sum = sub_rn(L[roff(j) + i], add_rn(add_rn(s0, s1), add_rn(s2, s3)));
+                }
+                if (j0 == i) {  // lane 0 holds the pivot of this row
+                    const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sum)));
+                    if (lane == 0 && !(piv > 0.f)) atomicAdd(a.spd_fail, 1u);
+                    p = sqrtf(piv);
+                }
+                if (j < k) L[roff(j) + i] = (j == i) ? p : sum / p;
+            }
+            __syncthreads();
+        }
     }
     // Triangular solves (column oriented; lane r owns row r, two rows per lane for k > 64).  The
     // pivots' reciprocals are taken once, in parallel, so that each of the 2k sequential steps is a
