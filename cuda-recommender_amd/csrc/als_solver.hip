@@ -40,6 +40,16 @@ __device__ __forceinline__ float add_rn(float a, float b) {
 }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 mul2_rn(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ f32x2 add2_rn(f32x2 a, f32x2 b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
 
 struct AlsArgs {
     const AlsItem* items;
@@ -61,41 +71,49 @@ template <int NT> struct Tiles { static constexpr int kCount = NT * (NT + 1) / 2
 template <int NT>
 __device__ __forceinline__ size_t slot_floats() { return (size_t) Tiles<NT>::kCount * 1024 + (size_t) NT * 64; }
 
-// Accumulators + rhs -> LDS, Cholesky, two triangular solves, Y[seg] <- solution.
+// LDS image of one system: the lower triangle only, rows packed back to back with every row start
+// rounded up to 4 floats (16-B aligned for ds_read_b128): 8.7 KB for k = 64 instead of 17.4 KB for
+// the square, which is what lets 16 instead of 9 single-wave workgroups share a CU.  The rhs follows.
+constexpr int roff_host(int r) { return 4 * ((r >> 2) + 1) * (2 * (r >> 2) + (r & 3)); }
+__device__ __forceinline__ int roff(int r) { const int g = r >> 2, m = r & 3; return 4 * (g + 1) * (2 * g + m); }
+
+// 32x32x2 accumulators (upper block triangle) + rhs -> LDS image.
 template <int NT>
-__device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], float* lds,
-                           const AlsArgs& a, uint32_t seg) {
+__device__ __forceinline__ void stage_tiles32(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], float* lds) {
     constexpr int KP = 32 * NT;
-    // Only the lower triangle is kept, rows packed back to back with every row start rounded up to
-    // 4 floats (16-B aligned for ds_read_b128): 8.7 KB for k = 64 instead of 17.4 KB for the square,
-    // which is what lets 16 instead of 9 single-wave workgroups share a CU.
-    auto roff = [](int r) { const int g = r >> 2, m = r & 3; return 4 * (g + 1) * (2 * g + m); };
     const uint32_t lane = threadIdx.x & 63, c31 = lane & 31, h = lane >> 5;
+    float* L = lds;
+    float* bv = lds + roff(KP);
+    int ti = 0;
+#pragma unroll
+    for (int I = 0; I < NT; ++I) {
+#pragma unroll
+        for (int J = I; J < NT; ++J, ++ti) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = I * 32 + (r & 3) + 8 * (r >> 2) + 4 * (int) h;
+                const int col = J * 32 + (int) c31;
+                const float x = acc[ti][r];
+                if (row >= col) L[roff(row) + col] = x;  // diagonal tiles hold both (r,c) and (c,r): same value
+                else L[roff(col) + row] = x;
+            }
+        }
+    }
+#pragma unroll
+    for (int I = 0; I < NT; ++I) {
+        const float t = bacc[I] + __shfl_xor(bacc[I], 32, 64);
+        if (h == 0) bv[I * 32 + c31] = t;
+    }
+}
+
+// LDS image -> + lambda, Cholesky, two triangular solves, Y[seg] <- solution.
+template <int NT>
+__device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
+    constexpr int KP = 32 * NT;
+    const uint32_t lane = threadIdx.x & 63;
     const int k = (int) a.k;
     float* L = lds;
     float* bv = lds + roff(KP);
-    {
-        int ti = 0;
-#pragma unroll
-        for (int I = 0; I < NT; ++I) {
-#pragma unroll
-            for (int J = I; J < NT; ++J, ++ti) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = I * 32 + (r & 3) + 8 * (r >> 2) + 4 * (int) h;
-                    const int col = J * 32 + (int) c31;
-                    const float x = acc[ti][r];
-                    if (row >= col) L[roff(row) + col] = x;  // diagonal tiles hold both (r,c) and (c,r): same value
-                    else L[roff(col) + row] = x;
-                }
-            }
-        }
-#pragma unroll
-        for (int I = 0; I < NT; ++I) {
-            const float t = bacc[I] + __shfl_xor(bacc[I], 32, 64);
-            if (h == 0) bv[I * 32 + c31] = t;
-        }
-    }
     __syncthreads();
     if (a.gram_out) {
         for (int e = (int) lane; e < k * k; e += 64) {
@@ -113,16 +131,22 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
     // reference's single accumulator would be a 64-deep dependent chain per row); products and sums
     // stay unfused.  Same arithmetic in both variants below, so they agree bit for bit.
     if constexpr (NT <= 2) {
-        // k <= 64: lane j keeps row j in registers.  Row i reaches the other lanes through
-        // v_readlane (static register, static lane after full unrolling), so the factorisation
-        // reads no LDS at all -- the LDS form below moves ~1 MB through the LDS pipe per system and
-        // was what bounded the user half-sweep (480 k systems).
-        float r[KP];
+        // k <= 64: lane j keeps its own row j in registers (static indices after full unrolling), so
+        // only row i -- the same for every lane -- is read from LDS, as broadcast ds_read_b128 of
+        // whole 4-column groups; the up to three columns past the last whole group come from lane
+        // i's registers by v_readlane.  Each finished column goes back to LDS with one ds_write_b32,
+        // so later rows find it there and the image is complete for the triangular solves.  Against
+        // reading both rows from LDS this halves the LDS traffic (which bounded the user half-sweep,
+        // 480 k systems) and drops the per-lane address arithmetic.
+        // Register pairs and explicit 2-wide products / sums: v_pk_mul_f32 + v_pk_add_f32 on naturally
+        // aligned pairs (left to itself the SLP vectoriser pairs non-adjacent columns and pays for it in v_mov).
+        f32x2 r2[KP / 2];
         const int row = (int) lane < KP ? (int) lane : KP - 1;  // KP = 32: the upper half-wave mirrors row 31, never stores
 #pragma unroll
         for (int q = 0; q < KP; q += 4) {  // reads past the end of a short row stay inside L; those slots are never used
-            const float4 x = *reinterpret_cast<const float4*>(&L[roff(row) + q]);
-            r[q] = x.x; r[q + 1] = x.y; r[q + 2] = x.z; r[q + 3] = x.w;
+            const f32x4 x = *reinterpret_cast<const f32x4*>(&L[roff(row) + q]);
+            r2[q / 2] = x.lo;
+            r2[q / 2 + 1] = x.hi;
         }
         auto rl = [](float x, int src_lane) {
             return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
@@ -130,28 +154,23 @@ __device__ void solve_tail(f32x16 (&acc)[Tiles<NT>::kCount], float (&bacc)[NT], 
 #pragma unroll
         for (int i = 0; i < KP; ++i) {
             if (i < k) {  // wave-uniform
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q + 4 <= i; q += 4) {
-                    s0 = add_rn(s0, mul_rn(rl(r[q], i), r[q]));
-                    s1 = add_rn(s1, mul_rn(rl(r[q + 1], i), r[q + 1]));
-                    s2 = add_rn(s2, mul_rn(rl(r[q + 2], i), r[q + 2]));
-                    s3 = add_rn(s3, mul_rn(rl(r[q + 3], i), r[q + 3]));
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(&L[roff(i) + q]);
+                    s01 = add2_rn(s01, mul2_rn(x.lo, r2[q / 2]));
+                    s23 = add2_rn(s23, mul2_rn(x.hi, r2[q / 2 + 1]));
                 }
 #pragma unroll
-                for (int q = i & ~3; q < i; ++q) s0 = add_rn(s0, mul_rn(rl(r[q], i), r[q]));
-                const float sum = sub_rn(r[i], add_rn(add_rn(s0, s1), add_rn(s2, s3)));
+                for (int q = i & ~3; q < i; ++q) s01.x = add_rn(s01.x, mul_rn(rl(r2[q / 2][q & 1], i), r2[q / 2][q & 1]));
+                const float sum = sub_rn(r2[i / 2][i & 1], add_rn(add_rn(s01.x, s01.y), add_rn(s23.x, s23.y)));
                 const float piv = rl(sum, i);
                 if (lane == 0 && !(piv > 0.f)) atomicAdd(a.spd_fail, 1u);
                 const float p = sqrtf(piv);
-                r[i] = (int) lane == i ? p : sum / p;  // lanes j < i write a slot (column i > j) they never read
+                const float lji = (int) lane == i ? p : sum / p;
+                r2[i / 2][i & 1] = lji;  // lanes j < i: a register slot (column i > j) they never read
+                if ((int) lane >= i && (int) lane < KP) L[roff((int) lane) + i] = lji;
             }
-        }
-        if ((int) lane < KP) {
-#pragma unroll
-            for (int q = 0; q < KP; q += 4)
-                if (q <= (int) lane)  // row j owns roundup4(j + 1) floats
-                    *reinterpret_cast<float4*>(&L[roff((int) lane) + q]) = make_float4(r[q], r[q + 1], r[q + 2], r[q + 3]);
         }
         __syncthreads();
     } else {
@@ -292,7 +311,8 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
         for (int I = 0; I < NT; ++I) w[Tiles<NT>::kCount * 1024 + I * 64 + lane] = bacc[I];
         return;
     }
-    solve_tail<NT>(acc, bacc, lds, a, it.seg);
+    stage_tiles32<NT>(acc, bacc, lds);
+    factor_solve<NT>(lds, a, it.seg);
 }
 
 template <int NT>
@@ -318,7 +338,164 @@ __global__ __launch_bounds__(64) void k_als_reduce(AlsArgs a) {
 #pragma unroll
         for (int I = 0; I < NT; ++I) bacc[I] += w[Tiles<NT>::kCount * 1024 + I * 64 + lane];
     }
-    solve_tail<NT>(acc, bacc, lds, a, rd.seg);
+    stage_tiles32<NT>(acc, bacc, lds);
+    factor_solve<NT>(lds, a, rd.seg);
+}
+
+// ---- 32 < k <= 64, k % 4 == 0: 16x16x4 tiles fed by 16-byte gathers ---------------------------------
+// Lane l = (g = l >> 4, c = l & 15) loads X[row(q0 + g)][4c .. 4c+3] with ONE global_load_dwordx4: a
+// wave instruction fetches four whole factor rows (1 KB) instead of two half rows (256 B), which is
+// what the L2 / Infinity Cache gather rate wants.  Register e of that float4 is column 4c + e; taken
+// as the A (and B) operand of v_mfma_f32_16x16x4_f32 (lane supplies A[i = c][kk = g]) it is "column
+// set e", so tile (e, e') accumulates G[4c + e][4c' + e'] -- the Gramian under a fixed column
+// permutation that stage_tiles16 undoes on the way to LDS.  10 of 16 tiles (upper triangle of the
+// 4 x 4 set grid) = 320 MFMA cycles per 4 rows, against 384 for 3 of 4 32x32 tiles.
+constexpr int kSets = 4, kTiles16 = kSets * (kSets + 1) / 2;
+
+__device__ __forceinline__ void stage_tiles16(f32x4 (&acc)[kTiles16], float (&bacc)[kSets], float* lds) {
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    float* L = lds;
+    float* bv = lds + roff(64);
+    int ti = 0;
+#pragma unroll
+    for (int e = 0; e < kSets; ++e) {
+#pragma unroll
+        for (int f = e; f < kSets; ++f, ++ti) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // accumulator register r of lane l is C[i = 4g + r][j = c]
+                const int row = 4 * (4 * (int) g + r) + e;
+                const int col = 4 * (int) c + f;
+                const float x = acc[ti][r];
+                if (row >= col) L[roff(row) + col] = x;
+                else L[roff(col) + row] = x;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kSets; ++e) {  // rhs: the four row groups hold partial sums of the same column
+        float t = bacc[e] + __shfl_xor(bacc[e], 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (g == 0) bv[4 * c + e] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_als_gram16(AlsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const uint32_t item = blockIdx.x;
+    if (item >= a.count) return;
+    const AlsItem it = a.items[item];
+    const uint32_t k = a.k;
+    if (it.hi == it.lo) {  // empty segment: zero vector (src/ALS.cpp:151-157)
+        for (uint32_t cc = lane; cc < k; cc += 64) a.Y[(size_t) it.seg * k + cc] = 0.f;
+        return;
+    }
+    f32x4 acc[kTiles16];
+    float bacc[kSets];
+#pragma unroll
+    for (int t = 0; t < kTiles16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < kSets; ++e) bacc[e] = 0.f;
+
+    constexpr int U = 4;  // 4-row steps per batch: 16 gathered rows (4 KB) in flight per wave, twice over
+    const bool col_ok = 4 * c < k;
+    // Two dependent round trips per batch (index -> factor row), both taken off the critical path:
+    // indices and ratings are fetched two batches ahead, factor rows one batch ahead.
+    uint32_t row_n[U];
+    float rv_n[U], rv_c[U];
+    f32x4 av_n[U];
+    auto load_idx = [&](uint32_t q0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 4 * u + g;
+            const bool ok = q < it.hi;
+            row_n[u] = ok ? a.idx[q] : 0u;
+            rv_n[u] = ok ? a.val[q] : 0.f;
+        }
+    };
+    auto load_rows = [&](uint32_t q0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool ok = col_ok && q0 + 4 * u + g < it.hi;
+            const f32x4* x = reinterpret_cast<const f32x4*>(a.X + (size_t) row_n[u] * k) + c;
+            av_n[u] = ok ? *x : f32x4{0.f, 0.f, 0.f, 0.f};
+            rv_c[u] = rv_n[u];
+        }
+    };
+    load_idx(it.lo);
+    load_rows(it.lo);
+    load_idx(it.lo + 4 * U);
+    for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 4 * U) {
+        f32x4 av[U];
+        float rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { av[u] = av_n[u]; rv[u] = rv_c[u]; }
+        load_rows(q0 + 4 * U);      // rows of the next batch (their indices arrived during the last one)
+        load_idx(q0 + 8 * U);       // indices of the batch after that
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int ti = 0;
+#pragma unroll
+            for (int e = 0; e < kSets; ++e) {
+                bacc[e] += rv[u] * av[u][e];
+#pragma unroll
+                for (int f = e; f < kSets; ++f, ++ti)
+                    acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], av[u][f], acc[ti], 0, 0, 0);
+            }
+        }
+    }
+    if (it.slot >= 0) {  // chunk of a long segment: park the raw accumulators, the reducer finishes
+        float* w = a.ws + (size_t) it.slot * slot_floats<2>();
+#pragma unroll
+        for (int t = 0; t < kTiles16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[t * 256 + r * 64 + lane] = acc[t][r];
+#pragma unroll
+        for (int e = 0; e < kSets; ++e) w[kTiles16 * 256 + e * 64 + lane] = bacc[e];
+        return;
+    }
+    stage_tiles16(acc, bacc, lds);
+    factor_solve<2>(lds, a, it.seg);
+}
+
+__global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    if (blockIdx.x >= a.count) return;
+    const AlsReduce rd = a.reduces[blockIdx.x];
+    f32x4 acc[kTiles16];
+    float bacc[kSets];
+#pragma unroll
+    for (int t = 0; t < kTiles16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < kSets; ++e) bacc[e] = 0.f;
+    for (uint32_t s = 0; s < rd.nslots; ++s) {  // chunk order: deterministic
+        const float* w = a.ws + (size_t) (rd.slot0 + s) * slot_floats<2>();
+#pragma unroll
+        for (int t = 0; t < kTiles16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += w[t * 256 + r * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < kSets; ++e) bacc[e] += w[kTiles16 * 256 + e * 64 + lane];
+    }
+    stage_tiles16(acc, bacc, lds);
+    factor_solve<2>(lds, a, rd.seg);
+}
+
+int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
+    const size_t lds_bytes = ((size_t) roff_host(64) + 64) * sizeof(float);
+    AlsArgs a = base;
+    if (nitems) {
+        a.count = nitems;
+        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_gram16, dim3(nitems), dim3(64), lds_bytes, st, a);
+        MFX_HIP(hipGetLastError());
+    }
+    if (nreduces) {
+        a.count = nreduces;
+        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_reduce16, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        MFX_HIP(hipGetLastError());
+    }
+    return MFX_OK;
 }
 
 template <int NT>
@@ -350,6 +527,7 @@ int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipS
 
 int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
     const uint32_t nt = (a.k + 31) / 32;
+    if (a.k > 32 && a.k <= 64 && a.k % 4 == 0) return launch_half_16(a, nitems, nreduces, st);  // 16-byte aligned factor rows
     switch (nt) {
         case 1: return launch_half_nt<1>(a, nitems, nreduces, st);
         case 2: return launch_half_nt<2>(a, nitems, nreduces, st);
