@@ -72,6 +72,10 @@ def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": False, "dtype": "f32",
                       "data": "synthetic", "config": {"workload": f"{host.rows}x{host.cols} nnz={Z} k={k}"},
                       "gramian_tflops": round(flops / (el / a.steps) / 1e12, 2),
+                      # whole iteration (Gramians + 2 x nseg Cholesky/solves) against the fp32 MFMA peak,
+                      # counting only the symmetric half of each Gramian as useful work
+                      "roofline": {"bound": "mfma", "achieved": round(flops / (el / a.steps) / 1e12, 2), "peak": 157.3,
+                                   "unit": "TFLOP/s", "frac": round(flops / (el / a.steps) / 1e12 / 157.3, 4), "traffic": None},
                       "kernels": {n: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1])} for n, v in kt.items()},
                       "rmse": [round(r.rmse, 6) for r in rep], "gen_seconds": round(gen_s, 2)}), flush=True)
     s.close()

@@ -1,19 +1,21 @@
 // als_solver.hip -- ALS kernels (gfx950) and host orchestration.
 //
 // Kernel shape.  One wavefront per work item; a work item is a whole segment, or a chunk of a long
-// one (AlsHalf::build).  The gathered factor rows go straight from global memory into the MFMA
-// operand layout: for v_mfma_f32_32x32x2_f32 lane l supplies A[i = l&31][kk = l>>5] and
-// B[kk = l>>5][j = l&31], so lane l loads X[row(q0 + (l>>5))][32*I + (l&31)] -- two gathered rows
-// per instruction, each read as contiguous 128-byte pieces.  The same register is the A operand
-// of tile (I, J) and the B operand of tile (J', I): no LDS staging, no cross-lane traffic.
-// Only the upper block triangle is accumulated (NT*(NT+1)/2 tiles of 16 accumulator registers).
-// fp32 MFMA is an exact k-ordered fmaf chain, so results are reproducible run to run.
+// one (AlsHalf::build).  The gathered factor rows go straight from global memory into an MFMA
+// operand layout -- no LDS staging, no cross-lane traffic:
+//   * 32 < k <= 64, k % 4 == 0: k_als_gram16 -- v_mfma_f32_16x16x4_f32 on "column sets", rows fetched
+//     with 16-byte loads, four whole rows per wave instruction (see the comment at the kernel);
+//   * any other k <= 128: k_als_gram<NT> -- v_mfma_f32_32x32x2_f32, lane l supplies A[i = l&31][kk = l>>5]
+//     and B[kk][j = l&31], so lane l loads X[row(q0 + (l>>5))][32*I + (l&31)]; the same register is
+//     the A operand of tile (I, J) and the B operand of tile (J', I).
+// Only the upper (block) triangle is accumulated.  fp32 MFMA is an exact k-ordered fmaf chain, so
+// results are reproducible run to run.
 //
 // Tail (per segment, still one wave): accumulators -> LDS (lower triangle only, rows packed and
 // 16-B aligned), + lambda on the diagonal (plain lambda, src/ALS.cpp:120-122), left-looking Cholesky
-// (the reference's row-by-row scheme, src/ALS.cpp:6-23, inner dot product in four partial sums via
-// ds_read_b128), then L z = b and L^T y = z instead of the reference's explicit inverse (same
-// solution up to rounding; tolerance in the tests).
+// (the reference's row-by-row scheme, src/ALS.cpp:6-23, inner dot product in four partial sums),
+// then L z = b and L^T y = z instead of the reference's explicit inverse (same solution up to
+// rounding; tolerance in the tests).
 #include "als_solver.hpp"
 
 #include <algorithm>
