@@ -157,6 +157,7 @@ def main() -> None:
     solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt if comm else None,
                            global_test_nnz=ntest_global, device_arrays=d)
     setup_s = time.time() - t0  # one-time: host-side panel layout build + upload
+    layout = solver.layout_info()
     W0 = mfx.initial_col(a.k, int(d["rows"]))  # reference init (glibc rand, seed 0), src/tools.cpp:165-173
     solver.set_factors(W0)
 
@@ -227,7 +228,7 @@ def main() -> None:
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
                         "algorithmic_bytes_per_launch": int(alg[dom]),
-                        "streamed_bytes_per_launch": int(phys[dom]) if (a.panel_rows >= 0 and dom in phys) else int(alg[dom]),
+                        "streamed_bytes_per_launch": int(phys[dom]) if (dom in phys and layout["csr" if "csr" in dom else "csc"]["kind"] == "lds") else int(alg[dom]),
                         "as_written_equiv_frac": round(a.k * (48 + 16 * a.inner) * nnz_global /
                                                        (elapsed / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
     kernels = {kn: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1]),
@@ -263,7 +264,7 @@ def main() -> None:
                        "inner_iters": a.inner, "schedule": "fused" if a.schedule == 1 else "as-written",
                        "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
-            "test_rmse_after": round(rmse_now, 6), "gen_seconds": round(gen_s, 2), "setup_seconds": round(setup_s, 2),
+            "layout": layout, "test_rmse_after": round(rmse_now, 6), "gen_seconds": round(gen_s, 2), "setup_seconds": round(setup_s, 2),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -106,6 +106,12 @@ int mfx_ccd_set_profile(mfx_ccd_t s, int on) {
     MFX_REQUIRE(s && s->impl, "null solver");
     return s->impl->set_profile(on != 0);
 }
+int mfx_ccd_layout_info(mfx_ccd_t s, int side, int32_t out[4]) {
+    MFX_REQUIRE(s && s->impl && out, "null argument");
+    MFX_REQUIRE(side == 0 || side == 1, "side must be 0 (CSC) or 1 (CSR)");
+    s->impl->layout_info(side, out);
+    return MFX_OK;
+}
 int mfx_ccd_destroy(mfx_ccd_t s) {
     if (!s) return MFX_OK;
     delete s->impl;
@@ -197,7 +203,7 @@ struct OpCtx {
 static FlatLayoutOptions op_layout(int variant, int64_t nseg, int64_t nnz, int64_t vec_len) {
     mfx_params p;
     mfx_params_default(&p);
-    p.panel_rows = variant >= 16 ? variant : variant == 2 ? 0 : -1;
+    p.panel_rows = (variant >= 16 || variant <= -16) ? variant : variant == 2 ? 0 : -1;
     return choose_layout(p, (uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, sizeof(float), variant == 0);
 }
 

@@ -159,7 +159,7 @@ struct FlatArgs {
     uint32_t panel_rows;
     uint32_t gather_len;
     uint32_t nne;
-    uint64_t nnz;  // plain layout: elements at or beyond nnz are padding
+    uint64_t nnz;  // plain layout: elements at or beyond nnz are padding (cache panels: = padded nnz)
     const void* gather;
     const void* perseg;
     float* gpart;
@@ -308,7 +308,10 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         const float vs[4] = {v.x, v.y, v.z, v.w};
         G ga[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ga[e] = LDS ? slice[ids[e]] : gather[ids[e]];
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (LDS) ga[e] = slice[ids[e]];
+            else ga[e] = ids[e] < a.gather_len ? gather[ids[e]] : zero_of(G{});  // cache panels pad with index G
+        }
         float vo[4], gc[4], hc[4];
 
         if (cur1_next == cur1) {
@@ -644,7 +647,7 @@ int launch_flat_lds(const SegStreamDev& s, const FlatArgs& a, uint32_t grid, siz
 template <int MODE>
 int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
     using G = typename ModeTraits<MODE>::G;
-    if (s.panel_rows == 0)
+    if (!s.lds_panels)
         return launch_flat_t<MODE, false, kBlock, false>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), 0, st);
     size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(G) + 15) / 16 * 16;
     if (ModeTraits<MODE>::kPerSeg) lds_bytes += (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
@@ -660,11 +663,12 @@ int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
 int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, int add,
                 hipStream_t st) {
     FlatArgs a;
-    a.idx = s.panel_rows ? static_cast<const void*>(s.idx16) : static_cast<const void*>(s.idx);
+    a.idx = s.lds_panels ? static_cast<const void*>(s.idx16) : static_cast<const void*>(s.idx);
     a.val = s.val; a.flags32 = s.flags32; a.hpre = s.hpre; a.seg_of_rank = s.seg_of_rank;
     a.wg_panel = s.wg_panel; a.nspans = s.nspans;
     a.tiles_per_span = s.tiles_per_span; a.panel_rows = s.panel_rows; a.gather_len = s.gather_len; a.nne = s.nne;
-    a.nnz = s.nnz; a.gather = gather; a.perseg = perseg; a.gpart = s.gpart; a.hpart = s.hpart;
+    // cache panels: padding sits at every panel's end and gathers a zero, so no tile is masked by position
+    a.nnz = (s.panel_rows && !s.lds_panels) ? s.padded_nnz : s.nnz; a.gather = gather; a.perseg = perseg; a.gpart = s.gpart; a.hpart = s.hpart;
     a.carry_g = s.carry_g; a.carry_h = s.carry_h; a.add = add;
     switch (mode) {
         case FM_SWEEP: return launch_flat_mode<FM_SWEEP>(s, a, st);

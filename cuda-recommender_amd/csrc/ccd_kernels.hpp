@@ -23,12 +23,13 @@ struct SegStreamDev {
     uint32_t tiles_per_span = 0;
     uint32_t npanels = 1;
     uint32_t panel_rows = 0;   // 0: plain layout, gather from global memory
+    bool lds_panels = false;   // panel_rows != 0: slices staged in LDS (16-bit local indices) or cache panels (global gather)
     uint32_t spans_per_wg = 1;
     uint32_t gather_len = 0;
     const uint32_t* ptr = nullptr;             // [nseg+1] input-order pointers (plain layout only)
     const uint32_t* ptr_v = nullptr;           // [npanels*nseg+1] virtual-segment pointers (stored coords)
     const uint32_t* seg_cnt = nullptr;         // [nseg]
-    const uint32_t* idx = nullptr;             // [padded nnz] gathered index (plain layout)
+    const uint32_t* idx = nullptr;             // [padded nnz] gathered index (plain layout, cache panels)
     const uint16_t* idx16 = nullptr;           // [padded nnz] panel-local gathered index (LDS panels)
     float* val = nullptr;                      // [padded nnz] residual copy, updated in place
     const uint32_t* flags32 = nullptr;         // [padded nnz / 32 + 16] head bits

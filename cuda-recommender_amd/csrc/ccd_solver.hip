@@ -53,7 +53,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
         MFX_REQUIRE(bad == ~0ull, "index %u at position %llu is out of range [0, %u)", idx_h[bad == ~0ull ? 0 : bad],
                     (unsigned long long) bad, G);
     }
-    if (opt.panel_rows) {
+    if (opt.panel_rows && opt.lds) {
         MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16,
                     "wg_waves must be 4, 8 or 16");
     }
@@ -79,7 +79,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_TRY(seg_cnt_.alloc(nseg));
     MFX_TRY(seg_cnt_.upload(L.seg_cnt.data(), nseg, MFX_HOST, st));
     std::vector<uint16_t> idx16;
-    if (L.panel_rows) {  // panel-local indices (and the zero slot, index panel_rows) fit 16 bits
+    if (L.panel_rows && L.lds) {  // panel-local indices (and the zero slot, index panel_rows) fit 16 bits
         MFX_REQUIRE(L.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
         idx16.resize(L.padded_nnz);
         struct Ctx { uint16_t* dst; const uint32_t* src; } cx{idx16.data(), L.idx_local.data()};
@@ -116,6 +116,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
 
     view.nseg = nseg; view.nne = L.nne; view.nnz = nnz; view.padded_nnz = L.padded_nnz; view.nspans = L.nspans;
     view.tiles_per_span = L.tiles_per_span; view.npanels = L.npanels; view.panel_rows = L.panel_rows;
+    view.lds_panels = L.panel_rows != 0 && L.lds;
     view.spans_per_wg = L.spans_per_wg; view.gather_len = G;
     view.ptr = ptr_.get(); view.ptr_v = ptr_v_.get(); view.seg_cnt = seg_cnt_.get(); view.idx = idx_.get();
     view.idx16 = idx16_.get();
@@ -138,7 +139,12 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     // 16 waves x 2 workgroups (64 KB of LDS each) = 32 resident waves per CU
     o.spans_per_wg = p.wg_waves > 0 ? (uint32_t) p.wg_waves : 16;
     o.panel_rows = 0;
-    if (need_plain || p.panel_rows < 0) return o;
+    if (need_plain || p.panel_rows == -1) return o;
+    if (p.panel_rows < -1) {  // explicit cache panels of -panel_rows entries
+        o.panel_rows = std::min<uint32_t>((uint32_t) -p.panel_rows, G ? G : 1u);
+        o.lds = false;
+        return o;
+    }
     // Small matrices: a pass is a few microseconds, the operand vectors live in L1/L2, and a 56 KB
     // slice load per workgroup would cost more than the streaming it serves (measured, ML-1M shape
     // k = 40: 0.86 ms per outer iteration plain vs 1.57 ms with panels; ML-10M shape: panels win 1.65x).
@@ -151,7 +157,19 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     if (pr >= G) pr = G;  // the whole gathered vector fits: one panel
     const uint64_t npanels = (G + pr - 1) / pr;
     const double mean_vseg = (double) nnz / ((double) npanels * (double) (nseg ? nseg : 1));
-    if (p.panel_rows == 0 && npanels > 1 && mean_vseg < 8.0) return o;  // would shred the segments
+    if (p.panel_rows == 0 && npanels > 1 && mean_vseg < 8.0) {
+        // LDS-sized panels would shred the segments (hyper-sparse shard: < 8 entries per (panel, segment)
+        // pair).  Cut at L2 granularity instead: 2 MB slices keep every gather an L2 hit (measured,
+        // tools/ubench_gather.hip sweep: 100 M 8-byte gathers take 0.60 ms against a 2 MB table, 1.01 ms
+        // against 8 MB), with whole segments of >= 8 entries per slice or not at all.
+        const uint32_t cpr = (2u << 20) / elem_bytes;
+        if (cpr >= G) return o;
+        const uint64_t cpanels = (G + cpr - 1) / cpr;
+        if ((double) nnz / ((double) cpanels * (double) (nseg ? nseg : 1)) < 8.0) return o;
+        o.panel_rows = cpr;
+        o.lds = false;
+        return o;
+    }
     o.panel_rows = pr;
     return o;
 }

@@ -73,6 +73,10 @@ public:
     int get_residual(float* csc_val, float* csr_val);
     KernelProfiler& profiler() { return prof_; }
     int set_profile(bool on);
+    void layout_info(int side, int32_t out[4]) const {
+        const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
+        out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
+    }
 
 private:
     CcdSolver() = default;

@@ -55,9 +55,10 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
     L.gather_len = G;
     L.nnz = nnz;
     L.panel_rows = opt.panel_rows;
+    L.lds = opt.panel_rows ? opt.lds : true;
     L.npanels = opt.panel_rows ? std::max(1u, (G + opt.panel_rows - 1) / opt.panel_rows) : 1u;
-    L.spans_per_wg = opt.panel_rows ? std::max(1u, opt.spans_per_wg) : 1u;
-    uint32_t tps = opt.tiles_per_span ? opt.tiles_per_span : pick_tiles_per_span(nnz, opt.panel_rows != 0);
+    L.spans_per_wg = (opt.panel_rows && opt.lds) ? std::max(1u, opt.spans_per_wg) : 1u;
+    uint32_t tps = opt.tiles_per_span ? opt.tiles_per_span : pick_tiles_per_span(nnz, opt.panel_rows != 0 && opt.lds);
     if (tps & 1) ++tps;  // the kernel consumes tiles in pairs
     L.tiles_per_span = tps;
     const uint64_t span = (uint64_t) tps * kTileElems;
@@ -104,7 +105,7 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
             for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) {
                 const uint32_t p = P == 1 ? 0u : idx[q] / PR;
                 const uint32_t d = cur[p]++;
-                L.idx_local[d] = idx[q] - p * PR;
+                L.idx_local[d] = L.lds ? idx[q] - p * PR : idx[q];
                 L.perm[d] = q;
             }
         }
@@ -138,8 +139,8 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
             L.max_wg_ranks = std::max(L.max_wg_ranks, hi - lo);
         }
     }
-    // 5. workgroup -> panel
-    if (PR) {
+    // 5. workgroup -> panel (LDS panels: a workgroup stages exactly one slice)
+    if (PR && L.lds) {
         const uint32_t nwg = L.nspans / L.spans_per_wg;
         L.wg_panel.assign(nwg, 0);
         uint32_t p = 0;

@@ -11,6 +11,12 @@
 //                   segment, then in the input's order), then panel 1, ...  Stored indices are
 //                   panel-local.  npanels == 1 and panel_rows == 0 is the plain layout (global
 //                   gather, input order).
+//   cache panel     (lds == false, panel_rows != 0) the same panel-major order, but with panels
+//                   sized for the L2 instead of LDS: indices stay global (32-bit), the kernel
+//                   gathers from global memory and only ever touches one ~2 MB slice of the
+//                   operand pack at a time.  For matrices whose segments are too short to be cut
+//                   into LDS-sized panels (hyper-sparse shards: every (panel, segment) pair would
+//                   hold < 1 entry).  Padding carries index G and gathers an exact zero.
 //   virtual segment (panel p, segment c) -> v = p * nseg + c; ptr_v[v] .. ptr_v[v+1] in the padded
 //                   panel-major coordinates.  Every panel is padded to a whole number of
 //                   workgroup chunks; the padding is folded into the panel's last virtual segment
@@ -43,6 +49,7 @@ struct FlatLayoutHost {
     uint32_t gather_len = 0;      // G: length of the gathered index space
     uint32_t npanels = 1;
     uint32_t panel_rows = 0;      // 0: plain layout (no LDS staging)
+    bool lds = true;              // panel_rows != 0: LDS panels (panel-local indices) or cache panels (global indices)
     uint32_t spans_per_wg = 1;
     uint32_t nne = 0;             // non-empty virtual segments
     uint32_t nspans = 0;
@@ -60,13 +67,14 @@ struct FlatLayoutHost {
     std::vector<uint32_t> idx_local;       // [padded_nnz] panel-local gathered index (pad: zero slot)
     std::vector<uint32_t> perm;            // [padded_nnz] input position of each stored element, ~0u for pad
     uint32_t span_len() const { return tiles_per_span * kTileElems; }
-    uint32_t pad_index() const { return panel_rows ? panel_rows : 0u; }
+    uint32_t pad_index() const { return panel_rows ? (lds ? panel_rows : gather_len) : 0u; }
 };
 
 struct FlatLayoutOptions {
     uint32_t tiles_per_span = 0;  // 0: choose
     uint32_t panel_rows = 0;      // 0: plain layout
-    uint32_t spans_per_wg = 1;    // waves per workgroup in the panel kernel
+    bool lds = true;              // false: cache panels (global indices, gather from L2)
+    uint32_t spans_per_wg = 1;    // waves per workgroup in the LDS-panel kernel
 };
 
 // ptr/idx are the input orientation (host pointers); G is the gathered dimension.

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mfx_ccd_get_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfx_ccd_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), f64p, i64p]),
     "mfx_ccd_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "mfx_ccd_layout_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "mfx_ccd_destroy": (C.c_int, [C.c_void_p]),
     "mfx_als_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(mfx_csx), C.POINTER(mfx_coo),
                                  C.POINTER(mfx_params), C.c_int]),

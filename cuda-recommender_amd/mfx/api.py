@@ -368,6 +368,16 @@ class CcdSolver:
     def set_profile(self, on: bool):
         L.check(L.lib().mfx_ccd_set_profile(self.handle, 1 if on else 0))
 
+    def layout_info(self):
+        """{"csc": {...}, "csr": {...}}: panels, entries per panel, kind ("lds" / "cache" / "plain"), tiles per span."""
+        out = {}
+        for side, name in ((0, "csc"), (1, "csr")):
+            v = (C.c_int32 * 4)()
+            L.check(L.lib().mfx_ccd_layout_info(self.handle, side, v))
+            out[name] = {"panels": int(v[0]), "panel_rows": int(v[1]),
+                         "kind": "lds" if v[2] else ("cache" if v[1] else "plain"), "tiles_per_span": int(v[3])}
+        return out
+
     def kernel_times(self):
         return _kernel_times(L.lib().mfx_ccd_kernel_times, self.handle)
 

@@ -82,9 +82,11 @@ typedef struct mfx_params {
     int32_t kernel_variant;    /* schedule 0 only: 0 = wave-per-segment kernels, 1 = flat-stream */
     int32_t profile;           /* 1: bracket every launch with HIP events (mfx_*_kernel_times) */
     int32_t tiles_per_span;    /* flat-stream span length / 256; 0 = choose from nnz */
-    int32_t panel_rows;        /* LDS panels: gathered entries staged per workgroup. 0 = choose (64 KB of
-                                  LDS per workgroup when segments stay long enough), -1 = off (gather from
-                                  L2), > 0 = explicit */
+    int32_t panel_rows;        /* panels of the gathered index space. 0 = choose (LDS panels, 64 KB of LDS per
+                                  workgroup, when segments stay long enough; else 2 MB cache panels served by
+                                  L2; else none), -1 = off (plain layout, gather from L2 / Infinity Cache),
+                                  > 0 = explicit LDS panel of that many entries, < -1 = explicit cache
+                                  panel of -panel_rows entries */
     int32_t wg_waves;          /* wavefronts per workgroup of the panel kernel: 4, 8 or 16; 0 = 16 */
     int32_t graph;             /* 0 = replay each outer iteration of the fused schedule as one hipGraph (single
                                   GPU, no per-launch profiling): removes host launch cost when the kernels are
@@ -157,6 +159,10 @@ int mfx_ccd_kernel_times(mfx_ccd_t s, int cap, const char** names, double* secon
                          int64_t* launches);
 /* Turns the per-launch event bracketing (mfx_params.profile) on or off between iterate calls. */
 int mfx_ccd_set_profile(mfx_ccd_t s, int on);
+/* Layout the solver chose for one residual copy (side 0 = CSC / column segments, 1 = CSR / row
+ * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 1 LDS panels /
+ * 0 cache panels or plain, out[3] = tiles per span.  For logs, benchmarks and tests. */
+int mfx_ccd_layout_info(mfx_ccd_t s, int side, int32_t out[4]);
 int mfx_ccd_destroy(mfx_ccd_t s);
 
 int mfx_als_create(mfx_als_t* out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
@@ -190,7 +196,8 @@ int mfx_als_destroy(mfx_als_t s);
  * src/CCD.cpp:110-113: out[c] = sum(vec[idx]*val) / (lambda*|Omega_c| + sum(vec[idx]^2)),
  * 0 for an empty segment.  variant: 0 = wave-per-segment kernel, 1 = flat-stream kernel gathering
  * from L2, 2 = flat-stream kernel with LDS panels (size chosen), >= 16 = LDS panels of `variant`
- * gathered entries (test hook: forces many panels on small inputs). */
+ * gathered entries, <= -16 = cache panels of `-variant` entries (test hooks: force many panels on
+ * small inputs). */
 int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx,
                        const float* val, int64_t vec_len, const float* vec, float lambda,
                        float* out, int variant, int device);

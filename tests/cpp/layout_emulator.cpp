@@ -26,7 +26,7 @@ static int check(uint32_t nseg, uint32_t G, const std::vector<uint32_t>& lens, c
     build_flat_layout(ptr.data(), idx.data(), nseg, nnz, G, opt, &L);
     const uint32_t span = L.span_len();
     if (L.padded_nnz % span || L.nspans != L.padded_nnz / span) { printf("span accounting\n"); return 1; }
-    if (opt.panel_rows && (L.nspans % L.spans_per_wg)) { printf("wg accounting\n"); return 1; }
+    if (opt.panel_rows && opt.lds && (L.nspans % L.spans_per_wg)) { printf("wg accounting\n"); return 1; }
     // every input position appears exactly once; stored index maps back to the input index
     std::vector<char> seen(nnz, 0);
     for (uint64_t e = 0; e < L.padded_nnz; ++e) {
@@ -35,11 +35,19 @@ static int check(uint32_t nseg, uint32_t G, const std::vector<uint32_t>& lens, c
         if (q >= nnz || seen[q]) { printf("perm not a bijection\n"); return 1; }
         seen[q] = 1;
         uint32_t panel = 0;
-        if (opt.panel_rows) {
+        if (opt.panel_rows && opt.lds) {
             panel = L.wg_panel[e / ((uint64_t) span * L.spans_per_wg)];
             if (L.idx_local[e] >= L.panel_rows) { printf("local index out of panel\n"); return 1; }
+            if (panel * L.panel_rows + L.idx_local[e] != idx[q]) { printf("index mapping\n"); return 1; }
+        } else {
+            if (L.idx_local[e] != idx[q]) { printf("global index mapping\n"); return 1; }
+            if (opt.panel_rows) {  // cache panels: stored position must lie inside the element's panel
+                panel = idx[q] / L.panel_rows;
+                if (e < L.ptr_v[(size_t) panel * nseg] || (panel + 1 < L.npanels && e >= L.ptr_v[(size_t) (panel + 1) * nseg])) {
+                    printf("element outside its cache panel\n"); return 1;
+                }
+            }
         }
-        if (panel * L.panel_rows + L.idx_local[e] != idx[q]) { printf("index mapping\n"); return 1; }
     }
     for (uint64_t q = 0; q < nnz; ++q) if (!seen[q]) { printf("missing element\n"); return 1; }
     // replay the kernel's span walk
@@ -101,6 +109,11 @@ int main() {
                     if (pr && (uint64_t) ((G + o.panel_rows - 1) / o.panel_rows) * tps * 256 * wg > 40000000ull) continue;
                     if (check(nseg, G, lens, o, rng)) { printf("FAILED trial %d tps %u pr %u wg %u\n", trial, tps, pr, wg); return 1; }
                     ++cases;
+                    if (pr && wg == 4) {  // the same cut as cache panels (global indices, no workgroup chunking)
+                        o.lds = false;
+                        if (check(nseg, G, lens, o, rng)) { printf("FAILED (cache panels) trial %d tps %u pr %u\n", trial, tps, pr); return 1; }
+                        ++cases;
+                    }
                 }
             }
         }

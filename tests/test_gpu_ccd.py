@@ -41,7 +41,7 @@ def relerr(a, b):
 
 
 # ------------------------------------------------------------------ single operators
-OP_VARIANTS = [0, 1, 2, 16, 100]  # wave-per-segment, flat/L2 gather, flat/LDS auto, LDS panels of 16 / 100 entries
+OP_VARIANTS = [0, 1, 2, 16, 100, -16, -100]  # wave-per-segment, flat/L2 gather, flat/LDS auto, LDS panels of 16 / 100 entries, cache panels
 
 
 @pytest.mark.parametrize("variant", OP_VARIANTS)
@@ -108,7 +108,7 @@ def test_flat_kernel_long_and_degenerate_segments(mfx, orc):
     per_seg = rng.uniform(-1, 1, lens.size).astype(np.float32)
     a = val.copy()
     orc.update_rating(ptr, idx, a, vec, per_seg, True, 2)
-    for variant in (1, 2, 16, 333):  # 333-entry panels: 16 panels, most of them cutting the long segment
+    for variant in (1, 2, 16, 333, -333):  # 333-entry panels: 16 panels, most of them cutting the long segment
         out = mfx.rank_one_sweep(ptr, idx, val, vec, 0.1, variant)
         assert relerr(out, ref) < 2e-5, variant
         assert np.all(out[lens == 0] == 0)
@@ -139,8 +139,9 @@ def _params(mfx, k, lam, t, T, schedule, variant, tiles=0, panel_rows=0, wg_wave
 
 
 # (schedule, kernel_variant, panel_rows): fused with LDS panels (auto = one panel here), fused with
-# tiny panels (many panels per matrix), fused gathering from L2, as-written wave, as-written flat
-SCHEDULES = [(1, 1, 0), (1, 1, 24), (1, 1, -1), (0, 0, 0), (0, 1, 0), (0, 1, 24)]
+# tiny panels (many panels per matrix), fused gathering from L2, as-written wave, as-written flat,
+# fused / as-written with tiny CACHE panels (panel-major order, global indices, gather from L2)
+SCHEDULES = [(1, 1, 0), (1, 1, 24), (1, 1, -1), (0, 0, 0), (0, 1, 0), (0, 1, 24), (1, 1, -24), (0, 1, -24)]
 
 
 @pytest.mark.parametrize("schedule,variant,panel_rows", SCHEDULES)
@@ -181,7 +182,7 @@ def test_residual_state_matches_reference(mfx, name, schedule, variant, panel_ro
 # ------------------------------------------------------------------ whole solves, ML-1M shape
 @pytest.mark.parametrize("schedule,variant,tiles,panel_rows,wg_waves", [
     (1, 1, 0, 0, 0), (1, 1, 2, 1000, 4), (1, 1, 16, 500, 16), (1, 1, 4, -1, 0), (1, 1, 8, 2048, 8),
-    (0, 0, 0, 0, 0), (0, 1, 4, 700, 8)])
+    (0, 0, 0, 0, 0), (0, 1, 4, 700, 8), (1, 1, 4, -700, 0), (1, 1, 0, -2000, 0)])
 def test_ccdpp_ml1m_shape_vs_oracle(mfx, orc, medium, schedule, variant, tiles, panel_rows, wg_waves):
     d, k, lam, t = medium, 40, 0.05, 3
     W0 = mfx.initial_col(k, d.rows)

@@ -60,7 +60,7 @@ def test_tiny_shapes(mfx, orc, rows, cols, nnz):
     key = rng.choice(rows * cols, size=nnz, replace=False)
     d = mfx.dataset.from_coo(rows, cols, key // cols, key % cols, rng.uniform(1, 5, nnz).astype(np.float32),
                              [0], [0], np.array([2.5], np.float32))
-    for kw in ({}, {"panel_rows": -1}, {"panel_rows": 16}, {"schedule": 0, "kernel_variant": 0}):
+    for kw in ({}, {"panel_rows": -1}, {"panel_rows": 16}, {"panel_rows": -16}, {"schedule": 0, "kernel_variant": 0}):
         _check(mfx, orc, d, 2, **kw)
 
 
@@ -84,7 +84,7 @@ def test_no_test_set_and_T_gt_1(mfx, orc):
     assert np.max(np.abs(W - Wr)) < 2e-3 * np.abs(Wr).max()
 
 
-@pytest.mark.parametrize("panel_rows", [999, 1000, 1001, 65535])
+@pytest.mark.parametrize("panel_rows", [999, 1000, 1001, 65535, -999, -1000, -1001])
 def test_panel_boundaries(mfx, orc, panel_rows):
     """Gathered dimension exactly at / one past a panel boundary; the largest 16-bit panel."""
     d = mfx.dataset.synth_ratings(1000, 1000, 40000, seed=9, skew=0.6, test_frac=0.01)
@@ -101,8 +101,21 @@ def test_many_one_entry_segments_overflow_the_lds_rank_window(mfx, orc):
     c = rng.integers(0, cols, rows)
     d = mfx.dataset.from_coo(rows, cols, r, c, rng.uniform(1, 5, rows).astype(np.float32),
                              r[:100], c[:100], np.full(100, 3.0, np.float32))
-    for kw in ({"panel_rows": 0}, {"panel_rows": 32}, {"panel_rows": -1}):
+    for kw in ({"panel_rows": 0}, {"panel_rows": 32}, {"panel_rows": -1}, {"panel_rows": -32}):
         _check(mfx, orc, d, 2, **kw)
+
+
+def test_hyper_sparse_shard_gets_cache_panels(mfx, orc):
+    """600 k x 40 k with 4.2 M ratings: LDS-sized panels would leave ~1 entry per (panel, column) pair,
+    so the column side must come out as 2 MB cache panels (global indices, L2 gather) and the row
+    side -- whose gathered vector is below 2 MB -- as the plain layout; results as the oracle's."""
+    d = mfx.dataset.synth_ratings(600000, 40000, 4200000, seed=21, skew=0.3, test_frac=0.002)
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2))
+    info = s.layout_info()
+    s.close()
+    assert info["csc"]["kind"] == "cache" and info["csc"]["panels"] == 3 and info["csc"]["panel_rows"] == 262144, info
+    assert info["csr"]["kind"] == "plain", info
+    _check(mfx, orc, d, 2, t=2)
 
 
 def test_bad_arguments_are_errors(mfx):

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -190,6 +191,19 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(vec, hv.data(), vmax * 8, hipMemcpyHostToDevice));
     CK(hipMemset(val, 0, nnz * 4));
 
+    if (argc > 2 && std::string(argv[2]) == "sweep") {
+        // global (L2 / Infinity Cache served) 8-byte gathers against the table size: what a panel cut
+        // at L2 granularity would buy for matrices whose segments are too short for LDS panels
+        std::vector<uint32_t> hs(nnz);
+        for (uint32_t vlen : {16384u, 65536u, 131072u, 262144u, 524288u, 1048576u}) {
+            uint64_t s = 1234567;
+            for (uint64_t i = 0; i < nnz; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; hs[i] = (uint32_t) (s % vlen); }
+            CK(hipMemcpy(idx, hs.data(), nnz * 4, hipMemcpyHostToDevice));
+            printf("---- vlen %u = %u KB table (uniform random) ----\n", vlen, vlen * 8 / 1024);
+            run<1, true, 2, 256>("global gather f2, nt, depth2", idx, val, vec, vlen, 12, nnz, out);
+        }
+        return 0;
+    }
     {   // 16-bit indices: 4 vs 8 elements per lane
         const uint32_t vlen = 7168;
         std::vector<uint16_t> h16(nnz);
