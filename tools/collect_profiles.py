@@ -15,6 +15,9 @@ for f in newest("stats", "*kernel_stats.csv"):
     rd = list(csv.reader(open(f)))
     rows = [rd[0]] + [r for r in rd[1:] if "mfx" in r[0]]
 csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w")).writerows(rows)
+for f in newest("stats_als", "*kernel_stats.csv"):
+    rd = list(csv.reader(open(f)))
+    csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats_als.csv"), "w")).writerows([rd[0]] + [r for r in rd[1:] if "mfx" in r[0]])
 with open(os.path.join(dst, f"{tag}_pmc.txt"), "w") as out:
     for d in ("fetch", "write", "l2", "sq"):
         out.write(f"== rocprofv3 --pmc pass: {d}\n")

@@ -7,5 +7,6 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py -
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/write.log 2>&1 || echo "write failed"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/l2 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/l2.log 2>&1 || echo "l2 failed"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $O/sq -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/sq.log 2>&1 || echo "sq failed"
-python3 bench.py --solver als --steps 2 --warmup 1 > $O/bench_als.log 2>&1
+python3 bench.py --solver als --steps 3 --warmup 1 > $O/bench_als.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_als -- python3 bench.py --solver als --steps 3 --warmup 1 > $O/stats_als.log 2>&1 || echo "als stats failed"
 grep '^{' $O/bench.log | tail -1 | cut -c1-400
