@@ -40,7 +40,7 @@ def test_gramian_golden(mfx, name):
     assert np.array_equal(A, A.T)
 
 
-@pytest.mark.parametrize("k", [5, 32, 40, 64, 100, 128])
+@pytest.mark.parametrize("k", [5, 32, 36, 40, 44, 60, 64, 68, 100, 128])
 def test_gramian_all_tile_counts(mfx, orc, k):
     rng = np.random.default_rng(k)
     X = rng.standard_normal((300, k)).astype(np.float32)
@@ -80,7 +80,7 @@ def test_als_matches_reference_golden(mfx, name):
     assert relerr(W, g["als__W"]) < 5e-3 and relerr(H, g["als__H"]) < 5e-3
 
 
-@pytest.mark.parametrize("k", [10, 40, 64, 128])
+@pytest.mark.parametrize("k", [10, 36, 40, 60, 64, 128])
 def test_als_medium_vs_oracle(mfx, orc, k):
     """Rows longer than one chunk (split Gramians + reducer), k across all tile counts."""
     d = mfx.dataset.synth_ratings(3000, 400, 150_000, seed=31 + k, skew=1.1, test_frac=0.01, empty_row_frac=0.02)
