@@ -204,6 +204,7 @@ static FlatLayoutOptions op_layout(int variant, int64_t nseg, int64_t nnz, int64
     mfx_params p;
     mfx_params_default(&p);
     p.panel_rows = (variant >= 16 || variant <= -16) ? variant : variant == 2 ? 0 : -1;
+    p.tile = -1;  // single operators: flat-stream layouts only
     return choose_layout(p, (uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, sizeof(float), variant == 0);
 }
 

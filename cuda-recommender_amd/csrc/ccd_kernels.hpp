@@ -39,6 +39,13 @@ struct SegStreamDev {
     const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id
     const uint32_t* wg_panel = nullptr;        // [nspans/spans_per_wg]
     const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding
+    // 2-D tile layout (tile_layout.hpp): replaces ptr_v / idx / flags / ranks above; val, perm, seg_cnt,
+    // nseg, nnz, padded_nnz, gather_len keep their meaning
+    bool tile = false;
+    uint32_t t_QB = 0, t_SR = 0, t_nB = 0, t_nP = 0, t_R = 1, t_stride = 0;
+    const uint32_t* t_code = nullptr;          // [padded nnz] (segment_local << 16) | index_local
+    const uint32_t* t_tile_sub = nullptr;      // [t_nB * t_nP + 1]
+    float2* t_gh_part = nullptr;               // [t_R][t_stride] strip partials written by the tile kernel
     // reduction scratch written by the flat kernels
     float* gpart = nullptr;    // [nne]
     float* hpart = nullptr;    // [nne]

@@ -9,6 +9,7 @@
 //     order of the two updates); only the order of the fp32 reduction differs from the CPU.
 //   * mfx_params.schedule = 0 runs the kernel sequence exactly as written, for A/B and parity.
 #include "ccd_solver.hpp"
+#include "tile_layout.hpp"
 
 #include <atomic>
 #include <cmath>
@@ -52,6 +53,10 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
         const uint64_t bad = cx.bad.load();
         MFX_REQUIRE(bad == ~0ull, "index %u at position %llu is out of range [0, %u)", idx_h[bad == ~0ull ? 0 : bad],
                     (unsigned long long) bad, G);
+    }
+    if (opt.tile_qb) {  // hyper-sparse orientation: 2-D tile order, unless the pattern does not suit it
+        TileLayoutHost T;
+        if (build_tile_layout(ptr_h, idx_h, nseg, nnz, G, opt.tile_qb, opt.tile_sr, opt.tile_max_pad, &T)) return build_tiles(T, val_h, st);
     }
     if (opt.panel_rows && opt.lds) {
         MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16,
@@ -130,6 +135,47 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     return MFX_OK;
 }
 
+int SegStreamStore::build_tiles(const TileLayoutHost& T, const float* val_h, hipStream_t st) {
+    std::vector<float> val_st(T.padded, 0.f);
+    if (val_h) {
+        struct Ctx { float* dst; const float* src; const uint32_t* perm; } cx{val_st.data(), val_h, T.perm.data()};
+        parallel_ranges_u64(T.padded, [](uint64_t b, uint64_t e, void* p) {
+            Ctx& c = *static_cast<Ctx*>(p);
+            for (uint64_t i = b; i < e; ++i)
+                if (c.perm[i] != ~0u) c.dst[i] = c.src[c.perm[i]];
+        }, &cx);
+    }
+    // strips: as many as fill the chip best (blocks x strips workgroups, one 1024-thread workgroup per CU)
+    int ncu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ncu = prop.multiProcessorCount;
+    }
+    uint32_t best_r = 1;
+    double best_fill = 0.0;
+    for (uint32_t r = 1; r <= 8 && r <= T.nP; ++r) {
+        const uint64_t wgs = (uint64_t) T.nB * r;
+        const double fill = (double) wgs / (double) (((wgs + ncu - 1) / ncu) * ncu);
+        if (fill > best_fill + 0.02) { best_fill = fill; best_r = r; }
+    }
+    const uint32_t stride = T.nB * T.QB;
+    MFX_TRY(seg_cnt_.alloc(T.nseg)); MFX_TRY(seg_cnt_.upload(T.seg_cnt.data(), T.nseg, MFX_HOST, st));
+    MFX_TRY(t_code_.alloc(T.padded)); MFX_TRY(t_code_.upload(T.code.data(), T.padded, MFX_HOST, st));
+    MFX_TRY(perm_.alloc(T.padded)); MFX_TRY(perm_.upload(T.perm.data(), T.padded, MFX_HOST, st));
+    MFX_TRY(val_.alloc(T.padded)); MFX_TRY(val_.upload(val_st.data(), T.padded, MFX_HOST, st));
+    MFX_TRY(t_tile_sub_.alloc(T.tile_sub.size())); MFX_TRY(t_tile_sub_.upload(T.tile_sub.data(), T.tile_sub.size(), MFX_HOST, st));
+    MFX_TRY(t_gh_part_.alloc_zero((size_t) best_r * stride, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    view = SegStreamDev();
+    view.nseg = T.nseg; view.nnz = T.nnz; view.padded_nnz = T.padded; view.gather_len = T.gather_len;
+    view.seg_cnt = seg_cnt_.get(); view.val = val_.get(); view.perm = perm_.get();
+    view.tile = true; view.t_QB = T.QB; view.t_SR = T.SR; view.t_nB = T.nB; view.t_nP = T.nP; view.t_R = best_r;
+    view.t_stride = stride; view.t_code = t_code_.get(); view.t_tile_sub = t_tile_sub_.get(); view.t_gh_part = t_gh_part_.get();
+    return MFX_OK;
+}
+
 // LDS panels pay off when the gathered vector is too big for L1 yet cutting it into LDS-sized
 // panels leaves virtual segments long enough to amortise the per-segment bookkeeping.
 FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz, uint32_t G, uint32_t elem_bytes,
@@ -140,6 +186,11 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     o.spans_per_wg = p.wg_waves > 0 ? (uint32_t) p.wg_waves : 16;
     o.panel_rows = 0;
     if (need_plain || p.panel_rows == -1) return o;
+    if (p.tile > 0) {  // forced 2-D tiles (test hook); what follows describes the fallback
+        o.tile_qb = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t) p.tile & 0xFFFFu, nseg ? nseg : 1u));
+        o.tile_sr = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t) p.tile >> 16, 5120u), G ? G : 1u));
+        o.tile_max_pad = 1.0;
+    }
     if (p.panel_rows < -1) {  // explicit cache panels of -panel_rows entries
         o.panel_rows = std::min<uint32_t>((uint32_t) -p.panel_rows, G ? G : 1u);
         o.lds = false;
@@ -162,6 +213,14 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
         // pair).  Cut at L2 granularity instead: 2 MB slices keep every gather an L2 hit (measured,
         // tools/ubench_gather.hip sweep: 100 M 8-byte gathers take 0.60 ms against a 2 MB table, 1.01 ms
         // against 8 MB), with whole segments of >= 8 entries per slice or not at all.
+        // Both operands in LDS (tile_layout.hpp): 16 B per segment (operand + accumulator) and two
+        // slices of the gathered pack share ~150 KB of one workgroup's LDS.
+        if (p.tile == 0 && nseg >= 2048) {
+            const uint32_t qb = std::min<uint32_t>(4608u, nseg);
+            uint32_t sr = (uint32_t) ((150u * 1024u - 16u * (qb + 1)) / (2u * elem_bytes)) / 256u * 256u;
+            sr = std::min<uint32_t>(std::min<uint32_t>(sr, 5120u), G);
+            if (sr >= 256) { o.tile_qb = qb; o.tile_sr = sr; }
+        }
         const uint32_t cpr = (2u << 20) / elem_bytes;
         if (cpr >= G) return o;
         const uint64_t cpanels = (G + cpr - 1) / cpr;

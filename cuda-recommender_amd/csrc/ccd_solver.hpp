@@ -29,6 +29,9 @@ private:
     DevBuf<float> val_, gpart_, hpart_, carry_g_, carry_h_;
     DevBuf<int32_t> rank_of_seg_;
     DevBuf<uint16_t> idx16_;
+    DevBuf<uint32_t> t_code_, t_tile_sub_;  // 2-D tile order
+    DevBuf<float2> t_gh_part_;
+    int build_tiles(const struct TileLayoutHost& T, const float* val_h, hipStream_t st);
 };
 
 // Panel size for an orientation whose largest LDS-staged pack element is `elem_bytes` wide:
@@ -75,6 +78,7 @@ public:
     int set_profile(bool on);
     void layout_info(int side, int32_t out[4]) const {
         const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
+        if (v.tile) { out[0] = (int32_t) v.t_nP; out[1] = (int32_t) v.t_SR; out[2] = 2; out[3] = (int32_t) v.t_QB; return; }
         out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
     }
 

@@ -75,6 +75,10 @@ struct FlatLayoutOptions {
     uint32_t panel_rows = 0;      // 0: plain layout
     bool lds = true;              // false: cache panels (global indices, gather from L2)
     uint32_t spans_per_wg = 1;    // waves per workgroup in the LDS-panel kernel
+    // 2-D tile order (tile_layout.hpp), tried FIRST when tile_qb != 0; the fields above then describe
+    // the fallback for patterns the tile builder refuses (a run longer than a sub-tile, too much padding)
+    uint32_t tile_qb = 0, tile_sr = 0;
+    double tile_max_pad = 0.25;   // refuse when more than this fraction of the stored slots would be padding
 };
 
 // ptr/idx are the input orientation (host pointers); G is the gathered dimension.

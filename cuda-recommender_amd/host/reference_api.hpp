@@ -36,7 +36,7 @@ inline mfx_params params_of(const parameter& p) {
     q.nBlocks = p.nBlocks; q.nThreadsPerBlock = p.nThreadsPerBlock;
     q.verbose = 1;  // the reference wrappers always print the per-iteration line
 #ifndef MFX_SHIM_EXTERNAL_TYPES  // knobs only this repository's `parameter` has
-    q.device = p.device; q.schedule = p.schedule; q.kernel_variant = p.kernel_variant; q.panel_rows = p.panel_rows;
+    q.device = p.device; q.schedule = p.schedule; q.kernel_variant = p.kernel_variant; q.panel_rows = p.panel_rows; q.tile = p.tile;
 #endif
     return q;
 }

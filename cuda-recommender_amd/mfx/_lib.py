@@ -33,7 +33,7 @@ class mfx_params(C.Structure):
                 ("nBlocks", C.c_uint32), ("nThreadsPerBlock", C.c_uint32), ("verbose", C.c_int32),
                 ("device", C.c_int32), ("schedule", C.c_int32), ("kernel_variant", C.c_int32),
                 ("profile", C.c_int32), ("tiles_per_span", C.c_int32), ("panel_rows", C.c_int32),
-                ("wg_waves", C.c_int32), ("graph", C.c_int32), ("reserved", C.c_int32 * 1)]
+                ("wg_waves", C.c_int32), ("graph", C.c_int32), ("tile", C.c_int32)]
 
 
 class mfx_iter_report(C.Structure):

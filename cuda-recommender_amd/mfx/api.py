@@ -57,6 +57,7 @@ class parameter:
         self.panel_rows = 0
         self.wg_waves = 0
         self.graph = 0
+        self.tile = 0
         self.log = 0  # print the reference's per-iteration "[-INFO-]" line
 
     def to_c(self) -> L.mfx_params:
@@ -67,6 +68,7 @@ class parameter:
         p.verbose, p.device, p.schedule = int(self.log), int(self.device), int(self.schedule)
         p.kernel_variant, p.profile, p.tiles_per_span = int(self.kernel_variant), int(self.profile), int(self.tiles_per_span)
         p.panel_rows, p.wg_waves, p.graph = int(self.panel_rows), int(self.wg_waves), int(self.graph)
+        p.tile = int(self.tile)
         return p
 
 
@@ -375,7 +377,8 @@ class CcdSolver:
             v = (C.c_int32 * 4)()
             L.check(L.lib().mfx_ccd_layout_info(self.handle, side, v))
             out[name] = {"panels": int(v[0]), "panel_rows": int(v[1]),
-                         "kind": "lds" if v[2] else ("cache" if v[1] else "plain"), "tiles_per_span": int(v[3])}
+                         "kind": "tile" if v[2] == 2 else "lds" if v[2] else ("cache" if v[1] else "plain"),
+                         "tiles_per_span": int(v[3])}  # kind "tile": panel_rows = slice entries, tiles_per_span = segments per block
         return out
 
     def kernel_times(self):

@@ -91,7 +91,9 @@ typedef struct mfx_params {
     int32_t graph;             /* 0 = replay each outer iteration of the fused schedule as one hipGraph (single
                                   GPU, no per-launch profiling): removes host launch cost when the kernels are
                                   only a few microseconds long; -1 = always launch eagerly */
-    int32_t reserved[1];
+    int32_t tile;              /* 2-D tile order for hyper-sparse shards (both operands in LDS): 0 = choose (when
+                                  LDS panels would leave < 8 entries per (panel, segment) pair), -1 = never,
+                                  > 0 = force it with (slice entries << 16) | segments per block (test hook) */
 } mfx_params;
 
 /* One outer iteration's numbers == the fields of the reference's log line
@@ -160,8 +162,9 @@ int mfx_ccd_kernel_times(mfx_ccd_t s, int cap, const char** names, double* secon
 /* Turns the per-launch event bracketing (mfx_params.profile) on or off between iterate calls. */
 int mfx_ccd_set_profile(mfx_ccd_t s, int on);
 /* Layout the solver chose for one residual copy (side 0 = CSC / column segments, 1 = CSR / row
- * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 1 LDS panels /
- * 0 cache panels or plain, out[3] = tiles per span.  For logs, benchmarks and tests. */
+ * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 2 tile order / 1 LDS
+ * panels / 0 cache panels or plain, out[3] = tiles per span (tile order: segments per block).  For logs,
+ * benchmarks and tests. */
 int mfx_ccd_layout_info(mfx_ccd_t s, int side, int32_t out[4]);
 int mfx_ccd_destroy(mfx_ccd_t s);
 

@@ -60,7 +60,8 @@ def test_tiny_shapes(mfx, orc, rows, cols, nnz):
     key = rng.choice(rows * cols, size=nnz, replace=False)
     d = mfx.dataset.from_coo(rows, cols, key // cols, key % cols, rng.uniform(1, 5, nnz).astype(np.float32),
                              [0], [0], np.array([2.5], np.float32))
-    for kw in ({}, {"panel_rows": -1}, {"panel_rows": 16}, {"panel_rows": -16}, {"schedule": 0, "kernel_variant": 0}):
+    for kw in ({}, {"panel_rows": -1}, {"panel_rows": 16}, {"panel_rows": -16}, {"schedule": 0, "kernel_variant": 0},
+               {"tile": (3 << 16) | 2}):
         _check(mfx, orc, d, 2, **kw)
 
 
@@ -101,21 +102,29 @@ def test_many_one_entry_segments_overflow_the_lds_rank_window(mfx, orc):
     c = rng.integers(0, cols, rows)
     d = mfx.dataset.from_coo(rows, cols, r, c, rng.uniform(1, 5, rows).astype(np.float32),
                              r[:100], c[:100], np.full(100, 3.0, np.float32))
-    for kw in ({"panel_rows": 0}, {"panel_rows": 32}, {"panel_rows": -1}, {"panel_rows": -32}):
+    for kw in ({"panel_rows": 0}, {"panel_rows": 32}, {"panel_rows": -1}, {"panel_rows": -32},
+               {"tile": (2000 << 16) | 3000}):  # 64 columns: a column's run inside a slice exceeds a sub-tile on the CSC side -> fallback there
         _check(mfx, orc, d, 2, **kw)
 
 
-def test_hyper_sparse_shard_gets_cache_panels(mfx, orc):
-    """600 k x 40 k with 4.2 M ratings: LDS-sized panels would leave ~1 entry per (panel, column) pair,
-    so the column side must come out as 2 MB cache panels (global indices, L2 gather) and the row
-    side -- whose gathered vector is below 2 MB -- as the plain layout; results as the oracle's."""
+def test_hyper_sparse_shard_layouts(mfx, orc):
+    """600 k x 40 k with 4.2 M ratings: LDS-sized panels would leave ~1 entry per (panel, segment) pair.
+    Default: both sides come out in the 2-D tile order (both operands in LDS).  With tiles off the column
+    side must fall back to 2 MB cache panels (global indices, L2 gather) and the row side -- whose
+    gathered vector is below 2 MB -- to the plain layout.  Results as the oracle's either way."""
     d = mfx.dataset.synth_ratings(600000, 40000, 4200000, seed=21, skew=0.3, test_frac=0.002)
     s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2))
+    info = s.layout_info()
+    s.close()
+    assert info["csc"]["kind"] == "tile" and info["csr"]["kind"] == "tile", info
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2, tile=-1))
     info = s.layout_info()
     s.close()
     assert info["csc"]["kind"] == "cache" and info["csc"]["panels"] == 3 and info["csc"]["panel_rows"] == 262144, info
     assert info["csr"]["kind"] == "plain", info
     _check(mfx, orc, d, 2, t=2)
+    _check(mfx, orc, d, 2, t=2, T=2)
+    _check(mfx, orc, d, 2, t=2, tile=-1)
 
 
 def test_bad_arguments_are_errors(mfx):
