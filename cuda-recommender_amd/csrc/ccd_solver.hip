@@ -213,14 +213,8 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
         // pair).  Cut at L2 granularity instead: 2 MB slices keep every gather an L2 hit (measured,
         // tools/ubench_gather.hip sweep: 100 M 8-byte gathers take 0.60 ms against a 2 MB table, 1.01 ms
         // against 8 MB), with whole segments of >= 8 entries per slice or not at all.
-        // Both operands in LDS (tile_layout.hpp): 16 B per segment (operand + accumulator) and two
-        // slices of the gathered pack share ~150 KB of one workgroup's LDS.
-        if (p.tile == 0 && nseg >= 2048) {
-            const uint32_t qb = std::min<uint32_t>(4608u, nseg);
-            uint32_t sr = (uint32_t) ((150u * 1024u - 16u * (qb + 1)) / (2u * elem_bytes)) / 256u * 256u;
-            sr = std::min<uint32_t>(std::min<uint32_t>(sr, 5120u), G);
-            if (sr >= 256) { o.tile_qb = qb; o.tile_sr = sr; }
-        }
+        // (The 2-D tile order of tile_layout.hpp -- both operands in LDS -- is NOT chosen here: at this
+        // density a slice serves too few entries; mfx_params.tile > 0 forces it.)
         const uint32_t cpr = (2u << 20) / elem_bytes;
         if (cpr >= G) return o;
         const uint64_t cpanels = (G + cpr - 1) / cpr;

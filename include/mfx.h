@@ -91,9 +91,9 @@ typedef struct mfx_params {
     int32_t graph;             /* 0 = replay each outer iteration of the fused schedule as one hipGraph (single
                                   GPU, no per-launch profiling): removes host launch cost when the kernels are
                                   only a few microseconds long; -1 = always launch eagerly */
-    int32_t tile;              /* 2-D tile order for hyper-sparse shards (both operands in LDS): 0 = choose (when
-                                  LDS panels would leave < 8 entries per (panel, segment) pair), -1 = never,
-                                  > 0 = force it with (slice entries << 16) | segments per block (test hook) */
+    int32_t tile;              /* experimental 2-D tile order for hyper-sparse shards (both operands in LDS,
+                                  csrc/tile_layout.hpp): 0 / -1 = off (default: measured slower than cache panels
+                                  at config 5's density), > 0 = (slice entries << 16) | segments per block */
 } mfx_params;
 
 /* One outer iteration's numbers == the fields of the reference's log line

@@ -108,23 +108,24 @@ def test_many_one_entry_segments_overflow_the_lds_rank_window(mfx, orc):
 
 
 def test_hyper_sparse_shard_layouts(mfx, orc):
-    """600 k x 40 k with 4.2 M ratings: LDS-sized panels would leave ~1 entry per (panel, segment) pair.
-    Default: both sides come out in the 2-D tile order (both operands in LDS).  With tiles off the column
-    side must fall back to 2 MB cache panels (global indices, L2 gather) and the row side -- whose
-    gathered vector is below 2 MB -- to the plain layout.  Results as the oracle's either way."""
+    """600 k x 40 k with 4.2 M ratings: LDS-sized panels would leave ~1 entry per (panel, segment) pair,
+    so the column side must come out as 2 MB cache panels (global indices, L2 gather) and the row side
+    -- whose gathered vector is below 2 MB -- as the plain layout.  The experimental 2-D tile order at
+    its production size must build on this pattern and agree as well.  Results as the oracle's."""
     d = mfx.dataset.synth_ratings(600000, 40000, 4200000, seed=21, skew=0.3, test_frac=0.002)
     s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2))
     info = s.layout_info()
     s.close()
-    assert info["csc"]["kind"] == "tile" and info["csr"]["kind"] == "tile", info
-    s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2, tile=-1))
-    info = s.layout_info()
-    s.close()
     assert info["csc"]["kind"] == "cache" and info["csc"]["panels"] == 3 and info["csc"]["panel_rows"] == 262144, info
     assert info["csr"]["kind"] == "plain", info
+    tile = (2304 << 16) | 4608
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2, tile=tile))
+    info = s.layout_info()
+    s.close()
+    assert info["csc"]["kind"] == "tile" and info["csr"]["kind"] == "tile", info
     _check(mfx, orc, d, 2, t=2)
-    _check(mfx, orc, d, 2, t=2, T=2)
-    _check(mfx, orc, d, 2, t=2, tile=-1)
+    _check(mfx, orc, d, 2, t=2, tile=tile)
+    _check(mfx, orc, d, 2, t=2, T=2, tile=tile)
 
 
 def test_bad_arguments_are_errors(mfx):
