@@ -12,15 +12,34 @@
 #include "tile_layout.hpp"
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <string>
+#include <thread>
 
 namespace mfx {
+
+namespace {
+// MFX_SETUP_TIMING=1 prints where the one-time layout build spends its time.
+struct PhaseTimer {
+    bool on = getenv("MFX_SETUP_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mfx setup] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx,
                           const float* val, mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st) {
     // The layout is built on the host (one pass over the pattern, a few threads); device-resident
     // inputs are brought down once for it.  One-time setup, outside every timed region.
+    PhaseTimer tm;
     std::vector<uint32_t> ptr_buf, idx_buf;
     std::vector<float> val_buf;
     const uint32_t* ptr_h = ptr;
@@ -39,6 +58,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
             val_h = val_buf.data();
         }
     }
+    tm.lap("inputs to host");
     MFX_REQUIRE(ptr_h[0] == 0 && ptr_h[nseg] == nnz, "segment pointer array does not span [0, nnz]");
     for (uint32_t c = 0; c < nseg; ++c)
         MFX_REQUIRE(ptr_h[c] <= ptr_h[c + 1], "segment pointer array is not monotone at %u", c);
@@ -62,19 +82,16 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
         MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16,
                     "wg_waves must be 4, 8 or 16");
     }
-    build_flat_layout(ptr_h, idx_h, nseg, nnz, G, opt, &layout_);
+    tm.lap("validation");
+    FlatLayoutOptions bopt = opt;  // one pass places indices (16-bit for LDS panels), provenance and values
+    bopt.emit_idx16 = opt.panel_rows != 0 && opt.lds;
+    bopt.emit_val = true;
+    bopt.val = val_h;
+    if (bopt.emit_idx16) MFX_REQUIRE(opt.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
+    build_flat_layout(ptr_h, idx_h, nseg, nnz, G, bopt, &layout_);
+    tm.lap("build_flat_layout");
     FlatLayoutHost& L = layout_;
     MFX_REQUIRE(L.padded_nnz < 0xFFFFFF00ull, "padded non-zero count exceeds the 32-bit position range");
-
-    std::vector<float> val_st(L.padded_nnz, 0.f);
-    if (val_h) {
-        struct Ctx { float* dst; const float* src; const uint32_t* perm; } cx{val_st.data(), val_h, L.perm.data()};
-        parallel_ranges_u64(L.padded_nnz, [](uint64_t b, uint64_t e, void* p) {
-            Ctx& c = *static_cast<Ctx*>(p);
-            for (uint64_t i = b; i < e; ++i)
-                if (c.perm[i] != ~0u) c.dst[i] = c.src[c.perm[i]];
-        }, &cx);
-    }
 
     const size_t nv = (size_t) L.npanels * nseg;
     MFX_TRY(ptr_.alloc((size_t) nseg + 1));
@@ -83,17 +100,9 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_TRY(ptr_v_.upload(L.ptr_v.data(), nv + 1, MFX_HOST, st));
     MFX_TRY(seg_cnt_.alloc(nseg));
     MFX_TRY(seg_cnt_.upload(L.seg_cnt.data(), nseg, MFX_HOST, st));
-    std::vector<uint16_t> idx16;
     if (L.panel_rows && L.lds) {  // panel-local indices (and the zero slot, index panel_rows) fit 16 bits
-        MFX_REQUIRE(L.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
-        idx16.resize(L.padded_nnz);
-        struct Ctx { uint16_t* dst; const uint32_t* src; } cx{idx16.data(), L.idx_local.data()};
-        parallel_ranges_u64(L.padded_nnz, [](uint64_t b, uint64_t e, void* p) {
-            Ctx& c = *static_cast<Ctx*>(p);
-            for (uint64_t i = b; i < e; ++i) c.dst[i] = (uint16_t) c.src[i];
-        }, &cx);
         MFX_TRY(idx16_.alloc(L.padded_nnz));
-        MFX_TRY(idx16_.upload(idx16.data(), L.padded_nnz, MFX_HOST, st));
+        MFX_TRY(idx16_.upload(L.idx16.data(), L.padded_nnz, MFX_HOST, st));
     } else {
         MFX_TRY(idx_.alloc(L.padded_nnz));
         MFX_TRY(idx_.upload(L.idx_local.data(), L.padded_nnz, MFX_HOST, st));
@@ -101,7 +110,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_TRY(perm_.alloc(L.padded_nnz));
     MFX_TRY(perm_.upload(L.perm.data(), L.padded_nnz, MFX_HOST, st));
     MFX_TRY(val_.alloc(L.padded_nnz));
-    MFX_TRY(val_.upload(val_st.data(), L.padded_nnz, MFX_HOST, st));
+    MFX_TRY(val_.upload(L.val_st.data(), L.padded_nnz, MFX_HOST, st));
     MFX_TRY(flags32_.alloc(L.flags32.size()));
     MFX_TRY(flags32_.upload(L.flags32.data(), L.flags32.size(), MFX_HOST, st));
     MFX_TRY(hpre_.alloc(L.hpre.size()));
@@ -118,6 +127,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_TRY(carry_h_.alloc_zero(L.nspans, st));
     // the host vectors behind the async uploads must outlive the copies
     MFX_HIP(hipStreamSynchronize(st));
+    tm.lap("allocations + uploads");
 
     view.nseg = nseg; view.nne = L.nne; view.nnz = nnz; view.padded_nnz = L.padded_nnz; view.nspans = L.nspans;
     view.tiles_per_span = L.tiles_per_span; view.npanels = L.npanels; view.panel_rows = L.panel_rows;
@@ -131,6 +141,8 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     view.carry_g = carry_g_.get(); view.carry_h = carry_h_.get();
     // the big host-side vectors are no longer needed
     for (auto* v : {&L.idx_local, &L.perm}) { v->clear(); v->shrink_to_fit(); }
+    L.idx16.clear(); L.idx16.shrink_to_fit();
+    L.val_st.clear(); L.val_st.shrink_to_fit();
     for (auto* v : {&L.flags32, &L.hpre}) { v->clear(); v->shrink_to_fit(); }
     return MFX_OK;
 }
@@ -332,10 +344,22 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // wave-per-segment kernels (schedule 0, variant 0) walk the input-order arrays
     const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
     // CSC side gathers the float2 pack (u_prev, u_cur) by row; CSR side the float4 pack by column
-    MFX_TRY(csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space,
-                       choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), st_));
-    MFX_TRY(csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space,
-                       choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), st_));
+    // The two orientations are independent: build them side by side (the serial stretches of one
+    // overlap the parallel passes of the other).  Error text is thread-local, so carry it across.
+    int rc_csr = MFX_OK;
+    std::string err_csr;
+    std::thread csr_thread([&] {
+        rc_csr = use_device(device_);
+        if (rc_csr == MFX_OK)
+            rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space,
+                                choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), st_);
+        if (rc_csr != MFX_OK) err_csr = last_error();
+    });
+    const int rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space,
+                                  choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), st_);
+    csr_thread.join();
+    if (rc_csc != MFX_OK) return rc_csc;
+    if (rc_csr != MFX_OK) { last_error() = err_csr; return rc_csr; }
 
     MFX_TRY(W_.alloc_zero((size_t) k_ * m_, st_));
     MFX_TRY(H_.alloc_zero((size_t) k_ * n_, st_));

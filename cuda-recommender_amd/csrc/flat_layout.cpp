@@ -33,6 +33,26 @@ void parallel_ranges(uint32_t n, F fn) {
     for (auto& x : th) x.join();
 }
 
+// Like parallel_ranges over segments, but the cuts balance the non-zeros (ptr is the prefix sum), so a
+// few heavy segments do not serialise the pass.
+template <typename F>
+void parallel_segments(const uint32_t* ptr, uint32_t nseg, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    const uint64_t nnz = ptr[nseg];
+    if (nseg < 64 || nnz < (1u << 16) || nt == 1) { fn(0u, nseg); return; }
+    std::vector<uint32_t> cut(nt + 1, nseg);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nt; ++t)
+        cut[t] = (uint32_t) (std::lower_bound(ptr, ptr + nseg + 1, (uint32_t) (nnz * t / nt)) - ptr);
+    for (unsigned t = 1; t <= nt; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
+    cut[nt] = nseg;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        if (cut[t + 1] > cut[t]) th.emplace_back([=] { fn(cut[t], cut[t + 1]); });
+    for (auto& x : th) x.join();
+}
+
 }  // namespace
 
 void parallel_ranges_u64(uint64_t n, void (*fn)(uint64_t, uint64_t, void*), void* ctx) {
@@ -69,11 +89,18 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
     // 1. entries per (panel, segment)
     std::vector<uint32_t> cnt(nv, 0);
     L.seg_cnt.resize(nseg);
-    parallel_ranges(nseg, [&](uint32_t b, uint32_t e) {
+    parallel_segments(ptr, nseg, [&](uint32_t b, uint32_t e) {
         for (uint32_t c = b; c < e; ++c) {
             L.seg_cnt[c] = ptr[c + 1] - ptr[c];
             if (P == 1) { cnt[c] = ptr[c + 1] - ptr[c]; continue; }
-            for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) ++cnt[(size_t) (idx[q] / PR) * nseg + c];
+            // panel of an index: the division is only taken when the index leaves the current panel,
+            // i.e. a handful of times per segment when the indices are ascending (the usual input)
+            uint32_t pp = 0, lo = 0, hi = PR;
+            for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) {
+                const uint32_t i = idx[q];
+                if (i < lo || i >= hi) { pp = i / PR; lo = pp * PR; hi = lo + PR; }
+                ++cnt[(size_t) pp * nseg + c];
+            }
         }
     });
     // 2. panel-major exclusive scan; every panel padded to whole workgroup chunks, the padding
@@ -94,22 +121,47 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
     L.padded_nnz = pos;
     L.nspans = (uint32_t) (pos / span);
 
-    // 3. stored order: panel-local indices + where every stored element came from
-    L.idx_local.assign(L.padded_nnz, L.pad_index());
-    L.perm.assign(L.padded_nnz, ~0u);
-    parallel_ranges(nseg, [&](uint32_t b, uint32_t e) {
+    // 3. stored order: panel-local indices + where every stored element came from (+ the values and
+    //    the 16-bit form of the indices if asked for).  The arrays are left uninitialised: every real
+    //    position is written by the placement below, the padding ranges right after.
+    const bool want16 = opt.emit_idx16 && PR != 0 && L.lds;
+    if (want16) L.idx16.resize(L.padded_nnz); else L.idx_local.resize(L.padded_nnz);
+    L.perm.resize(L.padded_nnz);
+    if (opt.emit_val) L.val_st.resize(L.padded_nnz);
+    uint32_t* const d_idx = want16 ? nullptr : L.idx_local.data();
+    uint16_t* const d_idx16 = want16 ? L.idx16.data() : nullptr;
+    uint32_t* const d_perm = L.perm.data();
+    float* const d_val = opt.emit_val ? L.val_st.data() : nullptr;
+    const float* const s_val = opt.val;
+    const bool local = L.lds;
+    parallel_segments(ptr, nseg, [&](uint32_t b, uint32_t e) {
         std::vector<uint32_t> cur(P);
         for (uint32_t c = b; c < e; ++c) {
             if (ptr[c + 1] == ptr[c]) continue;
             for (uint32_t p = 0; p < P; ++p) cur[p] = L.ptr_v[(size_t) p * nseg + c];
+            uint32_t p = 0, lo = 0, hi = P == 1 ? 0xFFFFFFFFu : PR;
             for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) {
-                const uint32_t p = P == 1 ? 0u : idx[q] / PR;
+                const uint32_t i = idx[q];
+                if (i < lo || i >= hi) { p = i / PR; lo = p * PR; hi = lo + PR; }
                 const uint32_t d = cur[p]++;
-                L.idx_local[d] = L.lds ? idx[q] - p * PR : idx[q];
-                L.perm[d] = q;
+                const uint32_t li = local ? i - lo : i;
+                if (d_idx16) d_idx16[d] = (uint16_t) li; else d_idx[d] = li;
+                d_perm[d] = q;
+                if (d_val) d_val[d] = s_val ? s_val[q] : 0.f;
             }
         }
     });
+    {   // padding: the tail of every panel (and of the whole stream)
+        const uint32_t pad = L.pad_index();
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint64_t end = p + 1 < P ? L.ptr_v[(size_t) (p + 1) * nseg] : L.padded_nnz;
+            for (uint64_t d = panel_real_end[p]; d < end; ++d) {
+                if (d_idx16) d_idx16[d] = (uint16_t) pad; else d_idx[d] = pad;
+                d_perm[d] = ~0u;
+                if (d_val) d_val[d] = 0.f;
+            }
+        }
+    }
 
     // 4. head flags, ranks and per-word head prefix counts over the virtual segments
     const size_t nwords = L.padded_nnz / 32;

@@ -38,11 +38,24 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace mfx {
 
 constexpr uint32_t kTileElems = 256;  // 64 lanes x 4 elements
+
+// std::vector whose resize() leaves trivially-constructible elements uninitialised: the big stored
+// arrays (hundreds of MB) are written exactly once, by the threads that place the non-zeros, instead of
+// being zero-filled -- and page-faulted in -- by one thread first.
+template <typename T>
+struct NoInitAllocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAllocator<U>; };
+    template <typename U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using HostVec = std::vector<T, NoInitAllocator<T>>;
 
 struct FlatLayoutHost {
     uint32_t nseg = 0;            // real segments (columns for CSC, rows for CSR)
@@ -64,8 +77,10 @@ struct FlatLayoutHost {
     std::vector<int32_t> rank_of_seg;      // [npanels*nseg], -1 for an empty virtual segment
     std::vector<uint32_t> seg_of_rank;     // [nne] REAL segment id of each rank
     std::vector<uint32_t> wg_panel;        // [nspans / spans_per_wg] (panel layout only)
-    std::vector<uint32_t> idx_local;       // [padded_nnz] panel-local gathered index (pad: zero slot)
-    std::vector<uint32_t> perm;            // [padded_nnz] input position of each stored element, ~0u for pad
+    HostVec<uint32_t> idx_local;           // [padded_nnz] panel-local gathered index (pad: zero slot); empty if idx16 was asked for
+    HostVec<uint16_t> idx16;               // [padded_nnz] the same as 16-bit values (FlatLayoutOptions::emit_idx16)
+    HostVec<uint32_t> perm;                // [padded_nnz] input position of each stored element, ~0u for pad
+    HostVec<float> val_st;                 // [padded_nnz] values in stored order, 0 for pad (FlatLayoutOptions::emit_val)
     uint32_t span_len() const { return tiles_per_span * kTileElems; }
     uint32_t pad_index() const { return panel_rows ? (lds ? panel_rows : gather_len) : 0u; }
 };
@@ -75,6 +90,11 @@ struct FlatLayoutOptions {
     uint32_t panel_rows = 0;      // 0: plain layout
     bool lds = true;              // false: cache panels (global indices, gather from L2)
     uint32_t spans_per_wg = 1;    // waves per workgroup in the LDS-panel kernel
+    // Optional outputs produced in the same pass that places the non-zeros (saves two more passes over
+    // hundreds of MB): 16-bit indices instead of idx_local (LDS panels only), values in stored order.
+    bool emit_idx16 = false;
+    bool emit_val = false;
+    const float* val = nullptr;   // input-order values for emit_val; nullptr = zeros
     // 2-D tile order (tile_layout.hpp), tried FIRST when tile_qb != 0; the fields above then describe
     // the fallback for patterns the tile builder refuses (a run longer than a sub-tile, too much padding)
     uint32_t tile_qb = 0, tile_sr = 0;
