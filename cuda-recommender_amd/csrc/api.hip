@@ -250,7 +250,7 @@ int mfx_update_rating(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint
     if (nnz) {
         DevBuf<float> tmp;
         MFX_TRY(tmp.alloc(nnz));
-        MFX_TRY(launch_unpermute(s.view, tmp.get(), cx.st));
+        MFX_TRY(s.unpermute(tmp.get(), cx.st));
         MFX_HIP(hipMemcpyAsync(val, tmp.get(), sizeof(float) * nnz, hipMemcpyDeviceToHost, cx.st));
         MFX_HIP(hipStreamSynchronize(cx.st));
     }

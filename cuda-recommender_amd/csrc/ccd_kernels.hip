@@ -7,6 +7,8 @@
 // (4) no atomics: every output has exactly one writer, so results are bitwise reproducible.
 #include "ccd_kernels.hpp"
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "flat_layout.hpp"
@@ -754,6 +756,24 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(uint64_t n, const uint32_t
     if (q != ~0u) out[q] = val[e];
 }
 
+// The same when every virtual segment is one run of consecutive input positions (flat_layout.hpp,
+// perm_is_runs): one wavefront per virtual segment, out[first_q[v] + k] = val[ptr_v[v] + k].
+__global__ __launch_bounds__(kBlock) void k_unpermute_runs(uint32_t nv, uint32_t nseg, const uint32_t* __restrict__ ptr_v,
+                                                           const uint32_t* __restrict__ first_q,
+                                                           const uint32_t* __restrict__ panel_end,
+                                                           const float* __restrict__ val, float* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+    for (uint32_t v = wave; v < nv; v += nwaves) {
+        const uint32_t lo = ptr_v[v], pe = panel_end[v / nseg];
+        uint32_t hi = ptr_v[v + 1];
+        if (hi > pe) hi = pe;  // a panel's last virtual segment also spans the padding
+        if (hi <= lo) continue;
+        const uint32_t q0 = first_q[v];
+        for (uint32_t k = lane; k < hi - lo; k += 64) out[q0 + k] = val[lo + k];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_pack2(uint32_t n, const float* __restrict__ x,
                                                   const float* __restrict__ y, float2* __restrict__ pack) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -969,6 +989,16 @@ int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st) {
     if (s.padded_nnz == 0) return MFX_OK;
     MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_unpermute, dim3((uint32_t) ((s.padded_nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        s.padded_nnz, s.perm, s.val, out);
+    MFX_LAUNCH_CHECK();
+    return MFX_OK;
+}
+
+int launch_unpermute_runs(const SegStreamDev& s, const uint32_t* first_q, const uint32_t* panel_end, float* out, hipStream_t st) {
+    const uint32_t nv = s.npanels * s.nseg;
+    if (nv == 0) return MFX_OK;
+    const uint32_t blocks = std::min<uint32_t>((nv + kBlock / 64 - 1) / (kBlock / 64), 65536u);
+    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_unpermute_runs, dim3(blocks), dim3(kBlock), 0, st, nv, s.nseg, s.ptr_v, first_q, panel_end,
+                       s.val, out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }

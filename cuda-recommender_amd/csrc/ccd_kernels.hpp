@@ -38,7 +38,7 @@ struct SegStreamDev {
     const int32_t* rank_of_seg = nullptr;      // [npanels*nseg]
     const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id
     const uint32_t* wg_panel = nullptr;        // [nspans/spans_per_wg]
-    const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding
+    const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding; nullptr: SegStreamStore::unpermute knows
     // 2-D tile layout (tile_layout.hpp): replaces ptr_v / idx / flags / ranks above; val, perm, seg_cnt,
     // nseg, nnz, padded_nnz, gather_len keep their meaning
     bool tile = false;
@@ -91,6 +91,9 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& a, hipStream_t st
 
 // out[perm[e]] = val[e] for every stored, non-padding element: residual back in input order.
 int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st);
+
+// Same for a layout without a perm array (flat_layout.hpp, perm_is_runs).
+int launch_unpermute_runs(const SegStreamDev& s, const uint32_t* first_q, const uint32_t* panel_end, float* out, hipStream_t st);
 
 // pack[i] = (x ? x[i] : 0, y[i])
 int launch_pack2(uint32_t n, const float* x, const float* y, float2* pack, hipStream_t st);

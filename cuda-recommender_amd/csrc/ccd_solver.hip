@@ -86,6 +86,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     FlatLayoutOptions bopt = opt;  // one pass places indices (16-bit for LDS panels), provenance and values
     bopt.emit_idx16 = opt.panel_rows != 0 && opt.lds;
     bopt.emit_val = true;
+    bopt.compact_perm = true;  // ascending indices (the usual input): no 4 B/nnz provenance array at all
     bopt.val = val_h;
     if (bopt.emit_idx16) MFX_REQUIRE(opt.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
     build_flat_layout(ptr_h, idx_h, nseg, nnz, G, bopt, &layout_);
@@ -107,8 +108,13 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
         MFX_TRY(idx_.alloc(L.padded_nnz));
         MFX_TRY(idx_.upload(L.idx_local.data(), L.padded_nnz, MFX_HOST, st));
     }
-    MFX_TRY(perm_.alloc(L.padded_nnz));
-    MFX_TRY(perm_.upload(L.perm.data(), L.padded_nnz, MFX_HOST, st));
+    if (L.perm_is_runs) {
+        first_q_host_.assign(L.first_q.begin(), L.first_q.end());
+        panel_end_host_.assign(L.panel_real_end.begin(), L.panel_real_end.end());
+    } else {
+        MFX_TRY(perm_.alloc(L.padded_nnz));
+        MFX_TRY(perm_.upload(L.perm.data(), L.padded_nnz, MFX_HOST, st));
+    }
     MFX_TRY(val_.alloc(L.padded_nnz));
     MFX_TRY(val_.upload(L.val_st.data(), L.padded_nnz, MFX_HOST, st));
     MFX_TRY(flags32_.alloc(L.flags32.size()));
@@ -140,11 +146,23 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     view.wg_panel = wg_panel_.get(); view.perm = perm_.get(); view.gpart = gpart_.get(); view.hpart = hpart_.get();
     view.carry_g = carry_g_.get(); view.carry_h = carry_h_.get();
     // the big host-side vectors are no longer needed
-    for (auto* v : {&L.idx_local, &L.perm}) { v->clear(); v->shrink_to_fit(); }
+    for (auto* v : {&L.idx_local, &L.perm, &L.first_q}) { v->clear(); v->shrink_to_fit(); }
     L.idx16.clear(); L.idx16.shrink_to_fit();
     L.val_st.clear(); L.val_st.shrink_to_fit();
     for (auto* v : {&L.flags32, &L.hpre}) { v->clear(); v->shrink_to_fit(); }
     return MFX_OK;
+}
+
+int SegStreamStore::unpermute(float* out, hipStream_t st) {
+    if (view.perm || view.tile) return launch_unpermute(view, out, st);
+    if (first_q_dev_.size() == 0 && !first_q_host_.empty()) {
+        MFX_TRY(first_q_dev_.alloc(first_q_host_.size()));
+        MFX_TRY(first_q_dev_.upload(first_q_host_.data(), first_q_host_.size(), MFX_HOST, st));
+        MFX_TRY(panel_end_dev_.alloc(panel_end_host_.size()));
+        MFX_TRY(panel_end_dev_.upload(panel_end_host_.data(), panel_end_host_.size(), MFX_HOST, st));
+        MFX_HIP(hipStreamSynchronize(st));
+    }
+    return launch_unpermute_runs(view, first_q_dev_.get(), panel_end_dev_.get(), out, st);
 }
 
 int SegStreamStore::build_tiles(const TileLayoutHost& T, const float* val_h, hipStream_t st) {
@@ -632,7 +650,7 @@ int CcdSolver::get_residual(float* csc_val, float* csr_val) {
     for (int side = 0; side < 2; ++side) {
         float* out = side == 0 ? csc_val : csr_val;
         if (!out || !nnz_) continue;
-        MFX_TRY(launch_unpermute(side == 0 ? csc_.view : csr_.view, tmp.get(), st_));
+        MFX_TRY((side == 0 ? csc_ : csr_).unpermute(tmp.get(), st_));
         MFX_HIP(hipMemcpyAsync(out, tmp.get(), sizeof(float) * nnz_, hipMemcpyDeviceToHost, st_));
         MFX_HIP(hipStreamSynchronize(st_));
     }

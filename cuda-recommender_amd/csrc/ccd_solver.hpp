@@ -22,6 +22,8 @@ public:
               mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st);
     SegStreamDev view;
     const FlatLayoutHost& layout() const { return layout_; }
+    // out[input position] = stored value, for every real entry (test / debug path: mfx_ccd_get_residual)
+    int unpermute(float* out, hipStream_t st);
 
 private:
     FlatLayoutHost layout_;
@@ -29,6 +31,9 @@ private:
     DevBuf<float> val_, gpart_, hpart_, carry_g_, carry_h_;
     DevBuf<int32_t> rank_of_seg_;
     DevBuf<uint16_t> idx16_;
+    // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
+    std::vector<uint32_t> first_q_host_, panel_end_host_;
+    DevBuf<uint32_t> first_q_dev_, panel_end_dev_;
     DevBuf<uint32_t> t_code_, t_tile_sub_;  // 2-D tile order
     DevBuf<float2> t_gh_part_;
     int build_tiles(const struct TileLayoutHost& T, const float* val_h, hipStream_t st);

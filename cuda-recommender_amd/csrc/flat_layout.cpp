@@ -1,6 +1,7 @@
 #include "flat_layout.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <thread>
 
 namespace mfx {
@@ -86,22 +87,33 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
     const uint32_t P = L.npanels, PR = L.panel_rows;
     const size_t nv = (size_t) P * nseg;
 
-    // 1. entries per (panel, segment)
+    // 1. entries per (panel, segment); with compact_perm also where each pair's run starts in the input
+    //    and whether every pair is ONE run there (each panel visited in one stretch per segment)
     std::vector<uint32_t> cnt(nv, 0);
     L.seg_cnt.resize(nseg);
+    if (opt.compact_perm) L.first_q.resize(nv);
+    uint32_t* const fq = opt.compact_perm ? L.first_q.data() : nullptr;
+    std::atomic<bool> grouped{true};
     parallel_segments(ptr, nseg, [&](uint32_t b, uint32_t e) {
+        bool ok = true;
         for (uint32_t c = b; c < e; ++c) {
             L.seg_cnt[c] = ptr[c + 1] - ptr[c];
-            if (P == 1) { cnt[c] = ptr[c + 1] - ptr[c]; continue; }
+            if (P == 1) { cnt[c] = ptr[c + 1] - ptr[c]; if (fq) fq[c] = ptr[c]; continue; }
             // panel of an index: the division is only taken when the index leaves the current panel,
             // i.e. a handful of times per segment when the indices are ascending (the usual input)
-            uint32_t pp = 0, lo = 0, hi = PR;
+            uint32_t pp = 0, lo = 0, hi = 0;
             for (uint32_t q = ptr[c]; q < ptr[c + 1]; ++q) {
                 const uint32_t i = idx[q];
-                if (i < lo || i >= hi) { pp = i / PR; lo = pp * PR; hi = lo + PR; }
+                if (i < lo || i >= hi) {
+                    pp = i / PR; lo = pp * PR; hi = lo + PR;
+                    const size_t v = (size_t) pp * nseg + c;
+                    if (cnt[v] != 0) ok = false;  // second visit of this panel
+                    else if (fq) fq[v] = q;
+                }
                 ++cnt[(size_t) pp * nseg + c];
             }
         }
+        if (!ok) grouped = false;
     });
     // 2. panel-major exclusive scan; every panel padded to whole workgroup chunks, the padding
     //    folded into the panel's last virtual segment
@@ -120,17 +132,20 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
     L.ptr_v[nv] = (uint32_t) pos;
     L.padded_nnz = pos;
     L.nspans = (uint32_t) (pos / span);
+    L.panel_real_end.assign(panel_real_end.begin(), panel_real_end.end());
+    L.perm_is_runs = opt.compact_perm && grouped.load();
+    if (!L.perm_is_runs) { L.first_q.clear(); L.first_q.shrink_to_fit(); }
 
     // 3. stored order: panel-local indices + where every stored element came from (+ the values and
     //    the 16-bit form of the indices if asked for).  The arrays are left uninitialised: every real
     //    position is written by the placement below, the padding ranges right after.
     const bool want16 = opt.emit_idx16 && PR != 0 && L.lds;
     if (want16) L.idx16.resize(L.padded_nnz); else L.idx_local.resize(L.padded_nnz);
-    L.perm.resize(L.padded_nnz);
+    if (!L.perm_is_runs) L.perm.resize(L.padded_nnz);
     if (opt.emit_val) L.val_st.resize(L.padded_nnz);
     uint32_t* const d_idx = want16 ? nullptr : L.idx_local.data();
     uint16_t* const d_idx16 = want16 ? L.idx16.data() : nullptr;
-    uint32_t* const d_perm = L.perm.data();
+    uint32_t* const d_perm = L.perm_is_runs ? nullptr : L.perm.data();
     float* const d_val = opt.emit_val ? L.val_st.data() : nullptr;
     const float* const s_val = opt.val;
     const bool local = L.lds;
@@ -146,7 +161,7 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
                 const uint32_t d = cur[p]++;
                 const uint32_t li = local ? i - lo : i;
                 if (d_idx16) d_idx16[d] = (uint16_t) li; else d_idx[d] = li;
-                d_perm[d] = q;
+                if (d_perm) d_perm[d] = q;
                 if (d_val) d_val[d] = s_val ? s_val[q] : 0.f;
             }
         }
@@ -157,7 +172,7 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
             const uint64_t end = p + 1 < P ? L.ptr_v[(size_t) (p + 1) * nseg] : L.padded_nnz;
             for (uint64_t d = panel_real_end[p]; d < end; ++d) {
                 if (d_idx16) d_idx16[d] = (uint16_t) pad; else d_idx[d] = pad;
-                d_perm[d] = ~0u;
+                if (d_perm) d_perm[d] = ~0u;
                 if (d_val) d_val[d] = 0.f;
             }
         }

@@ -81,6 +81,12 @@ struct FlatLayoutHost {
     HostVec<uint16_t> idx16;               // [padded_nnz] the same as 16-bit values (FlatLayoutOptions::emit_idx16)
     HostVec<uint32_t> perm;                // [padded_nnz] input position of each stored element, ~0u for pad
     HostVec<float> val_st;                 // [padded_nnz] values in stored order, 0 for pad (FlatLayoutOptions::emit_val)
+    // FlatLayoutOptions::compact_perm and every segment's entries grouped by panel in input order (true
+    // for ascending indices): `perm` stays empty; virtual segment v holds input positions first_q[v],
+    // first_q[v] + 1, ... over its real entries [ptr_v[v], min(ptr_v[v+1], panel_real_end[panel]))
+    bool perm_is_runs = false;
+    HostVec<uint32_t> first_q;             // [npanels*nseg] (only meaningful for non-empty virtual segments)
+    std::vector<uint32_t> panel_real_end;  // [npanels] end of each panel's real entries (before its padding)
     uint32_t span_len() const { return tiles_per_span * kTileElems; }
     uint32_t pad_index() const { return panel_rows ? (lds ? panel_rows : gather_len) : 0u; }
 };
@@ -94,6 +100,7 @@ struct FlatLayoutOptions {
     // hundreds of MB): 16-bit indices instead of idx_local (LDS panels only), values in stored order.
     bool emit_idx16 = false;
     bool emit_val = false;
+    bool compact_perm = false;    // see FlatLayoutHost::perm_is_runs
     const float* val = nullptr;   // input-order values for emit_val; nullptr = zeros
     // 2-D tile order (tile_layout.hpp), tried FIRST when tile_qb != 0; the fields above then describe
     // the fallback for patterns the tile builder refuses (a run longer than a sub-tile, too much padding)

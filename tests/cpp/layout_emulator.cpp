@@ -3,6 +3,7 @@
 // replays the per-span walk (head flags, ranks, part[] / carry[] ownership) element by element
 // and checks that finalize's recombination gives every segment's exact integer sum.
 // Built and run by tests/test_layout_cpu.py (no GPU needed).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -85,6 +86,37 @@ static int check(uint32_t nseg, uint32_t G, const std::vector<uint32_t>& lens, c
             for (uint32_t s = lo / span + 1; s <= (hi - 1) / span; ++s) got += carry[s];
         }
         if (got != ref || L.seg_cnt[c] != lens[c]) { printf("segment %u: got %lld want %lld\n", c, got, ref); return 1; }
+    }
+    // run-compressed provenance: with every segment's indices ascending the builder must drop `perm`
+    // and first_q / panel_real_end must reproduce it exactly
+    if (opt.spans_per_wg == 4 || !opt.panel_rows) {
+        std::vector<uint32_t> sidx(idx);
+        for (uint32_t c = 0; c < nseg; ++c) std::sort(sidx.begin() + ptr[c], sidx.begin() + ptr[c + 1]);
+        FlatLayoutOptions o2 = opt;
+        FlatLayoutHost A, B;
+        build_flat_layout(ptr.data(), sidx.data(), nseg, nnz, G, o2, &A);
+        o2.compact_perm = true;
+        build_flat_layout(ptr.data(), sidx.data(), nseg, nnz, G, o2, &B);
+        if (!B.perm_is_runs || !B.perm.empty()) { printf("ascending indices not recognised as runs\n"); return 1; }
+        if (A.ptr_v != B.ptr_v || A.idx_local.size() != B.idx_local.size()) { printf("compact build differs\n"); return 1; }
+        for (size_t e = 0; e < A.idx_local.size(); ++e) if (A.idx_local[e] != B.idx_local[e]) { printf("compact build: indices differ\n"); return 1; }
+        std::vector<uint32_t> rec(A.padded_nnz, ~0u);
+        for (size_t v = 0; v < (size_t) A.npanels * nseg; ++v) {
+            const uint32_t lo = B.ptr_v[v], hi = std::min(B.ptr_v[v + 1], B.panel_real_end[v / nseg]);
+            for (uint32_t k = 0; lo + k < hi; ++k) rec[lo + k] = B.first_q[v] + k;
+        }
+        for (size_t e = 0; e < A.padded_nnz; ++e) if (rec[e] != A.perm[e]) { printf("run-compressed perm differs at %zu\n", e); return 1; }
+        // and an input that visits a panel twice inside one segment must keep the full array
+        if (nnz >= 3 && A.npanels > 1) {
+            FlatLayoutHost Cc;
+            build_flat_layout(ptr.data(), idx.data(), nseg, nnz, G, o2, &Cc);
+            if (Cc.perm_is_runs) {  // legal only if the random indices happen to be grouped: verify via perm of the full build
+                for (size_t v = 0; v < (size_t) L.npanels * nseg; ++v) {
+                    const uint32_t lo = L.ptr_v[v], hi = std::min(L.ptr_v[v + 1], L.panel_real_end[v / nseg]);
+                    for (uint32_t k = 1; lo + k < hi; ++k) if (L.perm[lo + k] != L.perm[lo] + k) { printf("non-grouped input taken for runs\n"); return 1; }
+                }
+            }
+        }
     }
     return 0;
 }
