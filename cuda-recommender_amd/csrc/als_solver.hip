@@ -75,7 +75,8 @@ struct AlsArgs {
     uint32_t count;  // items (gram kernel) or reduces (reduce kernel)
     const uint32_t* idx;
     const float* val;
-    const float* X;
+    const float* X;    // [x_rows + 1][k]: row x_rows is all zeros (gather target of positions past a segment's end)
+    uint32_t x_rows;
     float* Y;
     uint32_t k;
     float lambda;
@@ -418,9 +419,17 @@ __global__ __launch_bounds__(64) void k_als_gram16(AlsArgs a) {
     for (int e = 0; e < kSets; ++e) bacc[e] = 0.f;
 
     constexpr int U = 4;  // 4-row steps per batch: 16 gathered rows (4 KB) in flight per wave, twice over
-    const bool col_ok = 4 * c < k;
     // Two dependent round trips per batch (index -> factor row), both taken off the critical path:
-    // indices and ratings are fetched two batches ahead, factor rows one batch ahead.
+    // indices and ratings are fetched two batches ahead, factor rows one batch ahead.  Every load is
+    // UNCONDITIONAL and nothing is masked afterwards: positions past the segment's end (clamped to its
+    // last entry for the index / rating loads) and lanes past column k gather from the all-zero row
+    // X[x_rows], so they add exact zeros.  With the loads inside divergent branches -- or selects on
+    // the loaded rows -- the compiler either drains the memory queue (s_waitcnt vmcnt(0)) in front of
+    // the MFMA block or moves the consumption up to the loads: either way load latency and matrix work
+    // serialise within a wave.
+    const uint32_t last = it.hi - 1;
+    const uint32_t cc = 4 * c < k ? c : 0u;
+    const bool col_ok = 4 * c < k;
     uint32_t row_n[U];
     float rv_n[U], rv_c[U];
     f32x4 av_n[U];
@@ -428,29 +437,27 @@ __global__ __launch_bounds__(64) void k_als_gram16(AlsArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t q = q0 + 4 * u + g;
-            const bool ok = q < it.hi;
-            row_n[u] = ok ? a.idx[q] : 0u;
-            rv_n[u] = ok ? a.val[q] : 0.f;
+            const uint32_t r = a.idx[q < last ? q : last];
+            row_n[u] = (col_ok && q < it.hi) ? r : a.x_rows;
+            rv_n[u] = a.val[q < last ? q : last];  // multiplies a zero row when q is past the end
         }
     };
-    auto load_rows = [&](uint32_t q0) {
+    auto load_rows = [&]() {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = col_ok && q0 + 4 * u + g < it.hi;
-            const f32x4* x = reinterpret_cast<const f32x4*>(a.X + (size_t) row_n[u] * k) + c;
-            av_n[u] = ok ? *x : f32x4{0.f, 0.f, 0.f, 0.f};
+            av_n[u] = *(reinterpret_cast<const f32x4*>(a.X + (size_t) row_n[u] * k) + cc);
             rv_c[u] = rv_n[u];
         }
     };
     load_idx(it.lo);
-    load_rows(it.lo);
+    load_rows();
     load_idx(it.lo + 4 * U);
     for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 4 * U) {
         f32x4 av[U];
         float rv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { av[u] = av_n[u]; rv[u] = rv_c[u]; }
-        load_rows(q0 + 4 * U);      // rows of the next batch (their indices arrived during the last one)
+        load_rows();                // rows of the next batch (their indices arrived during the last one)
         load_idx(q0 + 8 * U);       // indices of the batch after that
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -603,11 +610,11 @@ int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, const uint32_t* ptr_in, const 
     return MFX_OK;
 }
 
-int als_half_launch(const AlsHalf& h, const float* X, float* Y, uint32_t k, float lambda, float* ws,
+int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y, uint32_t k, float lambda, float* ws,
                     uint32_t* spd_fail, hipStream_t st) {
     AlsArgs a{};
     a.items = h.items.get(); a.reduces = h.reduces.get(); a.idx = h.idx.get(); a.val = h.val.get();
-    a.X = X; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
+    a.X = X; a.x_rows = x_rows; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
     return launch_half(a, h.nitems, h.nreduces, st);
 }
 
@@ -682,8 +689,9 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // W-half walks CSR rows with csr_val (src/ALS.cpp:132), H-half walks CSC columns
     MFX_TRY(rows_.build(lrows, nnz_rows, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, kAlsChunk, st_));
     MFX_TRY(cols_.build(lcols, nnz_cols, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, kAlsChunk, st_));
-    MFX_TRY(W_.alloc_zero((size_t) m_ * k_, st_));
-    MFX_TRY(H_.alloc_zero((size_t) n_ * k_, st_));
+    // one extra, all-zero row each: the Gramian kernel gathers it for positions past a segment's end
+    MFX_TRY(W_.alloc_zero(((size_t) m_ + 1) * k_, st_));
+    MFX_TRY(H_.alloc_zero(((size_t) n_ + 1) * k_, st_));
     MFX_TRY(ws_.alloc(std::max<size_t>(1, als_ws_floats(std::max(rows_.nslots, cols_.nslots), k_))));
     MFX_TRY(spd_fail_.alloc_zero(1, st_));
     nnz_test_ = T ? T->nnz : 0;
@@ -728,11 +736,11 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
     for (int it = 0; it < n_iter; ++it) {
         MFX_HIP(hipMemsetAsync(spd_fail_.get(), 0, sizeof(uint32_t), st_));
         MFX_HIP(hipEventRecord(ev_[0], st_));
-        MFX_TRY(als_half_launch(rows_, H_.get(), W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, ws_.get(),
+        MFX_TRY(als_half_launch(rows_, H_.get(), n_, W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, ws_.get(),
                                 spd_fail_.get(), st_));
         if (comm_) MFX_TRY(exchange(W_.get(), row_bounds_));
         MFX_HIP(hipEventRecord(ev_[1], st_));
-        MFX_TRY(als_half_launch(cols_, W_.get(), H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, ws_.get(),
+        MFX_TRY(als_half_launch(cols_, W_.get(), m_, H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, ws_.get(),
                                 spd_fail_.get(), st_));
         if (comm_) MFX_TRY(exchange(H_.get(), col_bounds_));
         MFX_HIP(hipEventRecord(ev_[2], st_));
@@ -817,13 +825,13 @@ int als_gramian_op(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const floa
     DevBuf<uint32_t> didx, fail_cnt; DevBuf<float> dval, dX, dY, dA; DevBuf<AlsItem> ditem;
     MFX_TRY(didx.alloc(cnt)); MFX_TRY(didx.upload(idx, cnt, MFX_HOST, os.st));
     MFX_TRY(dval.alloc_zero(cnt, os.st));
-    MFX_TRY(dX.alloc((size_t) nrows_x * k)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
+    MFX_TRY(dX.alloc_zero(((size_t) nrows_x + 1) * k, os.st)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
     MFX_TRY(dY.alloc_zero(k, os.st)); MFX_TRY(dA.alloc_zero((size_t) k * k, os.st));
     MFX_TRY(fail_cnt.alloc_zero(1, os.st));
     AlsItem it{0, 0, (uint32_t) cnt, -1};
     MFX_TRY(ditem.alloc(1)); MFX_TRY(ditem.upload(&it, 1, MFX_HOST, os.st));
     AlsArgs a{};
-    a.items = ditem.get(); a.idx = didx.get(); a.val = dval.get(); a.X = dX.get(); a.Y = dY.get();
+    a.items = ditem.get(); a.idx = didx.get(); a.val = dval.get(); a.X = dX.get(); a.x_rows = (uint32_t) nrows_x; a.Y = dY.get();
     a.k = (uint32_t) k; a.lambda = 0.f; a.spd_fail = fail_cnt.get(); a.gram_out = dA.get();
     MFX_TRY(launch_half(a, 1, 0, os.st));
     MFX_HIP(hipMemcpyAsync(A, dA.get(), sizeof(float) * k * k, hipMemcpyDeviceToHost, os.st));
@@ -840,11 +848,11 @@ int als_half_op(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* 
     AlsHalf h;
     MFX_TRY(h.build((uint32_t) nseg, (uint64_t) nnz, ptr, idx, val, MFX_HOST, kAlsChunk, os.st));
     DevBuf<float> dX, dY, ws; DevBuf<uint32_t> fail_cnt;
-    MFX_TRY(dX.alloc((size_t) nrows_x * k)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
+    MFX_TRY(dX.alloc_zero(((size_t) nrows_x + 1) * k, os.st)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
     MFX_TRY(dY.alloc_zero((size_t) nseg * k, os.st));
     MFX_TRY(ws.alloc(std::max<size_t>(1, als_ws_floats(h.nslots, (uint32_t) k))));
     MFX_TRY(fail_cnt.alloc_zero(1, os.st));
-    MFX_TRY(als_half_launch(h, dX.get(), dY.get(), (uint32_t) k, lambda, ws.get(), fail_cnt.get(), os.st));
+    MFX_TRY(als_half_launch(h, dX.get(), (uint32_t) nrows_x, dY.get(), (uint32_t) k, lambda, ws.get(), fail_cnt.get(), os.st));
     MFX_HIP(hipMemcpyAsync(Y, dY.get(), sizeof(float) * (size_t) nseg * k, hipMemcpyDeviceToHost, os.st));
     MFX_HIP(hipStreamSynchronize(os.st));
     return MFX_OK;

@@ -72,8 +72,9 @@ private:
     int64_t n_half_[2] = {0, 0};
 };
 
-// Launches one half-sweep: Y[seg] = argmin over segment `seg` given factor rows X.
-int als_half_launch(const AlsHalf& h, const float* X, float* Y, uint32_t k, float lambda, float* ws,
+// Launches one half-sweep: Y[seg] = argmin over segment `seg` given factor rows X[x_rows + 1][k],
+// whose last row must be all zeros.
+int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y, uint32_t k, float lambda, float* ws,
                     uint32_t* spd_fail, hipStream_t st);
 // floats of workspace needed for `nslots` partial slots at rank k
 size_t als_ws_floats(uint32_t nslots, uint32_t k);
