@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (not part of the test suite; run on a GPU box):
+random shapes / densities / skews / ranks / layouts / schedules, CCD++ and ALS against the CPU oracle.
+
+    python3 tools/fuzz_parity.py [--cases N] [--seed S] [--seconds T]
+"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cuda-recommender_amd"))
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime in the process: before libmfx)
+import mfx
+from oracle import oracle as orc
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=200)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--seconds", type=float, default=240.0)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+t_end = time.time() + a.seconds
+fails, done, kinds = [], 0, {}
+for case in range(a.cases):
+    if time.time() > t_end:
+        break
+    rows = int(rng.choice([1, 3, 17, 64, 300, 1500, 9000, 40000]))
+    cols = int(rng.choice([1, 2, 40, 257, 1000, 5000, 30000]))
+    dens = float(rng.choice([0.0005, 0.003, 0.02, 0.1, 0.3]))
+    nnz = int(min(0.3 * rows * cols, max(1, rows * cols * dens), 400000))
+    if nnz < 1:
+        continue
+    d = mfx.dataset.synth_ratings(rows, cols, nnz, seed=int(rng.integers(1 << 30)), skew=float(rng.choice([0.0, 0.5, 1.2])),
+                                  test_frac=float(rng.choice([0.0, 0.02])), empty_row_frac=float(rng.choice([0.0, 0.1])))
+    k = int(rng.choice([1, 2, 5, 8, 16, 33]))
+    lam = float(rng.choice([0.01, 0.05, 0.5]))
+    T = int(rng.choice([1, 1, 2, 3]))
+    t = int(rng.choice([1, 2, 3]))
+    p = mfx.parameter(); p.k, p.lambda_, p.maxiter, p.maxinneriter = k, lam, t, T
+    lay = rng.choice(["auto", "plain", "lds", "cache", "tile", "wave", "written_flat"])
+    if lay == "plain": p.panel_rows = -1
+    elif lay == "lds": p.panel_rows = int(rng.choice([16, 100, 1000, 7000]))
+    elif lay == "cache": p.panel_rows = -int(rng.choice([16, 100, 5000]))
+    elif lay == "tile": p.tile = (int(rng.choice([3, 50, 900, 4608])) << 16) | int(rng.choice([2, 64, 1000, 4608]))
+    elif lay == "wave": p.schedule, p.kernel_variant = 0, 0
+    elif lay == "written_flat": p.schedule, p.kernel_variant, p.panel_rows = 0, 1, int(rng.choice([0, 50, -50]))
+    p.tiles_per_span = int(rng.choice([0, 2, 4, 16]))
+    p.wg_waves = int(rng.choice([0, 4, 8, 16]))
+    p.graph = int(rng.choice([0, -1]))
+    tag = f"case {case}: {rows}x{cols} nnz={d.nnz} k={k} T={T} t={t} {lay} pr={p.panel_rows} tile={p.tile} tps={p.tiles_per_span} wg={p.wg_waves}"
+    try:
+        W0 = mfx.initial_col(k, d.rows)
+        Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, T, 2)
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), p)
+        info = s.layout_info()
+        s.set_factors(W0.copy())
+        rep = s.iterate(t)
+        W, H = s.get_factors()
+        csc, csr = s.get_residual(d.nnz)
+        s.close()
+        kinds[info["csc"]["kind"]] = kinds.get(info["csc"]["kind"], 0) + 1
+        scale = max(1e-6, float(np.abs(Wr).max()), float(np.abs(Hr).max()))
+        err = max(float(np.abs(W - Wr).max()), float(np.abs(H - Hr).max())) / scale
+        rerr = float(np.abs(np.array([r.rmse for r in rep]) - rmse_ref).max()) if d.nnz_test else 0.0
+        res = max(float(np.abs(csc - csc_ref).max()), float(np.abs(csr - csr_ref).max())) if d.nnz else 0.0
+        if not (err < 1e-2 and rerr < 1e-4 and res < 5e-3 * max(1.0, float(np.abs(csc_ref).max()) if d.nnz else 1.0)):
+            fails.append(f"CCD {tag}: factor err {err:.2e} rmse err {rerr:.2e} residual err {res:.2e}")
+        # ALS on the same data (every 3rd case): one half-sweep against a float64 solve of the same normal
+        # equations on a sample of segments.  (Whole ALS runs are compared with the oracle in the test suite
+        # on well-posed shapes; on shapes with fewer informative rows than k two fp32 trajectories drift apart
+        # whatever the arithmetic, see tools/als_conditioning.py.)
+        if case % 3 == 0 and d.nnz > 0:
+            ka = int(rng.choice([3, 8, 20, 36, 40, 64, 70, 128]))
+            H0 = mfx.initial_col(d.cols, ka)
+            Y = mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, ka, lam)
+            Yo = orc.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, ka, lam, 2)
+            segs = rng.choice(d.rows, size=min(d.rows, 800), replace=False)
+            H64 = H0.astype(np.float64)
+            e_gpu = e_orc = 0.0
+            sc = 1e-12
+            for srow in segs:
+                lo, hi = int(d.csr_row_ptr[srow]), int(d.csr_row_ptr[srow + 1])
+                if hi == lo:
+                    if np.any(Y[srow] != 0):
+                        fails.append(f"ALS k={ka} {tag}: empty row {srow} not zero")
+                    continue
+                xs = H64[d.csr_col_idx[lo:hi]]
+                ref = np.linalg.solve(xs.T @ xs + lam * np.eye(ka), xs.T @ d.csr_val[lo:hi].astype(np.float64))
+                sc = max(sc, float(np.abs(ref).max()))
+                e_gpu = max(e_gpu, float(np.abs(Y[srow] - ref).max()))
+                e_orc = max(e_orc, float(np.abs(Yo[srow] - ref).max()))
+            if not (np.isfinite(e_gpu) and e_gpu <= max(5.0 * e_orc, 2e-4 * sc)):
+                fails.append(f"ALS k={ka} {tag}: |gpu-f64| {e_gpu / sc:.2e} vs |oracle-f64| {e_orc / sc:.2e}")
+    except Exception as ex:  # noqa: BLE001
+        fails.append(f"EXC {tag}: {type(ex).__name__}: {ex}")
+    done += 1
+    if done % 20 == 0:
+        print(f"{done} cases, {len(fails)} failures, layouts {kinds}", flush=True)
+print(f"fuzz: {done} cases, {len(fails)} failures, layouts {kinds}")
+for f in fails[:40]:
+    print("  " + f)
+sys.exit(1 if fails else 0)
