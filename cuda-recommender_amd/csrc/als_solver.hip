@@ -278,38 +278,48 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
 #pragma unroll
     for (int I = 0; I < NT; ++I) bacc[I] = 0.f;
 
-    constexpr int U = 8;  // gathered row pairs in flight per wave
-    // Two dependent memory round trips per step (index -> factor row).  The indices and ratings of
-    // step s+1 are fetched before the MFMAs of step s, so only the row gather's latency is exposed.
+    constexpr int U = NT >= 3 ? 4 : 8;  // gathered row pairs per batch (two batches in flight)
+    // Same pipeline as k_als_gram16: indices / ratings two batches ahead, factor rows one batch ahead,
+    // every load unconditional -- positions past the segment's end and columns past k gather from the
+    // all-zero row X[x_rows].
+    const uint32_t last = it.hi - 1;
     uint32_t row_n[U];
-    float rv_n[U];
+    float rv_n[U], rv_c[U];
+    float av_n[U][NT];
+    auto load_idx = [&](uint32_t q0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const uint32_t q = it.lo + 2 * u + h;
-        const bool ok = q < it.hi;
-        row_n[u] = ok ? a.idx[q] : 0u;
-        rv_n[u] = ok ? a.val[q] : 0.f;
-    }
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 2 * u + h;
+            const uint32_t r = a.idx[q < last ? q : last];
+            row_n[u] = q < it.hi ? r : a.x_rows;
+            rv_n[u] = a.val[q < last ? q : last];
+        }
+    };
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int I = 0; I < NT; ++I) {
+                const uint32_t col = I * 32 + c31;
+                const bool in = col < k;
+                av_n[u][I] = a.X[(size_t) (in ? row_n[u] : a.x_rows) * k + (in ? col : 0u)];
+            }
+            rv_c[u] = rv_n[u];
+        }
+    };
+    load_idx(it.lo);
+    load_rows();
+    load_idx(it.lo + 2 * U);
     for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 2 * U) {
         float av[U][NT], rv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = q0 + 2 * u + h < it.hi;
-            rv[u] = rv_n[u];
-            const float* x = a.X + (size_t) row_n[u] * k;
+            rv[u] = rv_c[u];
 #pragma unroll
-            for (int I = 0; I < NT; ++I) {
-                const uint32_t col = I * 32 + c31;
-                av[u][I] = (ok && col < k) ? x[col] : 0.f;
-            }
+            for (int I = 0; I < NT; ++I) av[u][I] = av_n[u][I];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + 2 * U + 2 * u + h;
-            const bool ok = q < it.hi;
-            row_n[u] = ok ? a.idx[q] : 0u;
-            rv_n[u] = ok ? a.val[q] : 0.f;
-        }
+        load_rows();
+        load_idx(q0 + 4 * U);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int ti = 0;
