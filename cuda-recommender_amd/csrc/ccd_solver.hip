@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <exception>
 #include <string>
 #include <thread>
 
@@ -366,15 +367,25 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // overlap the parallel passes of the other).  Error text is thread-local, so carry it across.
     int rc_csr = MFX_OK;
     std::string err_csr;
+    // (host allocations of several GB can fail: no exception may leave a thread or cross the C ABI)
     std::thread csr_thread([&] {
-        rc_csr = use_device(device_);
-        if (rc_csr == MFX_OK)
-            rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space,
-                                choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), st_);
+        try {
+            rc_csr = use_device(device_);
+            if (rc_csr == MFX_OK)
+                rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space,
+                                    choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), st_);
+        } catch (const std::exception& ex) {
+            rc_csr = fail(MFX_ERR_ALLOC, "building the CSR copy failed: %s", ex.what());
+        }
         if (rc_csr != MFX_OK) err_csr = last_error();
     });
-    const int rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space,
-                                  choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), st_);
+    int rc_csc;
+    try {
+        rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space,
+                            choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), st_);
+    } catch (const std::exception& ex) {
+        rc_csc = fail(MFX_ERR_ALLOC, "building the CSC copy failed: %s", ex.what());
+    }
     csr_thread.join();
     if (rc_csc != MFX_OK) return rc_csc;
     if (rc_csr != MFX_OK) { last_error() = err_csr; return rc_csr; }
