@@ -194,6 +194,30 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
         }
         if (lane == 0 && !spd_ok) atomicAdd(a.spd_fail, 1u);  // one count per system (the k > 64 form counts pivots)
         __syncthreads();
+        // Triangular solves, same arithmetic as the generic loops below but unrolled: the forward pass
+        // takes L[lane][i] from the lane's registers, the backward pass reads row i of L from LDS at a
+        // compile-time offset (lane-strided, conflict-free); no per-step address arithmetic.
+        float z = lane < (uint32_t) k ? bv[lane] : 0.f;
+        const float rp = lane < (uint32_t) k ? 1.0f / L[roff((int) lane) + lane] : 0.f;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {  // forward: L z = b
+            if (i < k) {
+                const float zi = rl(z, i) * rl(rp, i);
+                const float upd = sub_rn(z, mul_rn(r2[i / 2][i & 1], zi));
+                z = (int) lane == i ? zi : ((int) lane > i && (int) lane < k ? upd : z);
+            }
+        }
+#pragma unroll
+        for (int i = KP - 1; i >= 0; --i) {  // backward: L^T y = z
+            if (i < k) {
+                const float yi = rl(z, i) * rl(rp, i);
+                const float lij = L[roff(i) + ((int) lane < i ? (int) lane : 0)];
+                const float upd = sub_rn(z, mul_rn(lij, yi));
+                z = (int) lane == i ? yi : ((int) lane < i ? upd : z);
+            }
+        }
+        if ((int) lane < k) a.Y[(size_t) seg * k + lane] = z;
+        return;
     } else {
         // k > 64: rows do not fit the register file next to the accumulators; row i is a broadcast
         // ds_read_b128, row j lane-strided and conflict-free.
