@@ -107,6 +107,8 @@ def main() -> None:
                     help="skip the second, event-bracketed pass (use under rocprofv3 --kernel-trace: the "
                          "event packets between launches otherwise end up inside its kernel durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rank-one", action="store_true",
+                    help="skip the standalone rank-one sweep measurement (one extra outer iteration at T = 2, N = 1 only)")
     ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
     a = ap.parse_args()
 
@@ -238,6 +240,31 @@ def main() -> None:
     rep = solver.iterate(1, with_rmse=True)  # one more iteration, just to report a test RMSE
     rmse_now = rep[0].rmse
 
+    # ---------------- the rank-one sweep on its own (B_r1 = 8 B/nnz per half-sweep) -------
+    # In the default schedule at T = 1 the first sweep of every rank is fused into the two passes; the
+    # standalone kernel only runs for inner iterations 2..T.  One outer iteration at T = 2 on a second
+    # solver over the same resident inputs gives its launch time: k v-sweeps (CSC copy) + k u-sweeps (CSR).
+    rank_one = None
+    if world == 1 and not a.no_rank_one and not a.no_event_pass and a.schedule == 1:
+        solver.close()
+        p2 = mfx.parameter()
+        p2.k, p2.lambda_, p2.maxinneriter, p2.device = a.k, a.lam, 2, local_rank
+        p2.schedule, p2.kernel_variant, p2.tiles_per_span = a.schedule, a.variant, a.tiles
+        p2.panel_rows, p2.wg_waves, p2.graph, p2.tile, p2.profile = a.panel_rows, a.wg_waves, -1, a.tile, 1
+        s2 = mfx.CcdSolver(None, None, p2, device_arrays=d)
+        s2.set_factors(W0)
+        s2.iterate(1, with_rmse=False)
+        kt2 = s2.kernel_times()
+        s2.close()
+        if "ccd_flat_sweep" in kt2:
+            secs, launches = kt2["ccd_flat_sweep"]
+            avg = secs / max(1, launches)
+            b_r1 = 8.0 * Z + 0.5 * ((4.0 * (n + 1) + 4.0 * m + 4.0 * n) + (4.0 * (m + 1) + 4.0 * n + 4.0 * m))  # mean of the two sides
+            rank_one = {"kernel": "ccd_flat_sweep", "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
+                        "algorithmic_bytes_per_launch": int(b_r1), "achieved": round(b_r1 / avg / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(b_r1 / avg / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "standalone v-/u-sweep launches of one outer iteration at T = 2 (inner iteration 2)"}
+
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) --------
     cpu_baseline = None
     if world == 1 and not a.no_cpu_baseline:
@@ -252,7 +279,7 @@ def main() -> None:
         cpu_baseline = {"value": round(host.nnz / t_outer_k, 1), "unit": "nnz/s", "cores": threads, "kind": "port",
                         "sample": f"{ks} of {a.k} ranks, outer iterations 1-2 on the full matrix; steady-state "
                                   f"iteration 2 ({t_steady:.2f} s) scaled by {a.k}/{ks}"}
-    solver.close()
+    solver.close()  # (idempotent)
 
     if rank == 0:
         out = {
@@ -264,7 +291,7 @@ def main() -> None:
                        "rows_per_gpu": a.rows, "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
                        "inner_iters": a.inner, "schedule": "fused" if a.schedule == 1 else "as-written",
                        "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "rank_one_kernel": rank_one, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "layout": layout, "test_rmse_after": round(rmse_now, 6), "gen_seconds": round(gen_s, 2), "setup_seconds": round(setup_s, 2),
         }
         print(json.dumps(out), flush=True)
