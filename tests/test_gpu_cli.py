@@ -2,6 +2,7 @@
 import os
 import re
 import struct
+import sys
 import subprocess
 
 import numpy as np
@@ -73,3 +74,25 @@ def test_mfx_train_multi_shard(tmp_path):
     m, n = struct.unpack("<qq", raw[:16])
     W = np.frombuffer(raw[16:16 + 4 * m * n], np.float32).reshape(m, n).T
     assert np.max(np.abs(W - g["ccd_T1__W"])) < 2e-3 * np.max(np.abs(g["ccd_T1__W"]))
+
+
+def test_bench_contract_line():
+    """bench.py on a small shape: ONE JSON line on stdout with the contract keys, the roofline /
+    rank_one_kernel / cpu_baseline objects and the layout report."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "20000", "--cols", "3000", "--nnz", "5000000",
+                          "--k", "8", "--steps", "2", "--warmup", "1", "--cpu-ranks", "2"],
+                         check=True, capture_output=True, text=True, timeout=600).stdout
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "nnz/s" and d["vs_baseline"] is None
+    assert abs(d["value"] - 5000000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["rank_one_kernel"]["kernel"] == "ccd_flat_sweep" and d["rank_one_kernel"]["launches"] == 16
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["layout"]["csc"]["kind"] in ("lds", "cache", "plain")
