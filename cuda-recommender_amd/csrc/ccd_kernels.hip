@@ -164,10 +164,8 @@ struct FlatArgs {
     uint64_t nnz;  // plain layout: elements at or beyond nnz are padding (cache panels: = padded nnz)
     const void* gather;
     const void* perseg;
-    float* gpart;
-    float* hpart;
-    float* carry_g;
-    float* carry_h;
+    float2* part;   // [nne] (g, h) of every non-empty virtual segment, written by the span holding its head
+    float2* carry;  // [nspans] (g, h) of a span's leading run that continues an earlier span's segment
     int add;
 };
 
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         if (live < ntiles) ntiles = live;
     }
     if (ntiles == 0) {  // nothing stored here (plain layout, nnz == 0): still own the carry slot
-        if (TR::kDot && lane == 0) { a.carry_g[span] = 0.f; a.carry_h[span] = 0.f; }
+        if (TR::kDot && lane == 0) a.carry[span] = make_float2(0.f, 0.f);
         return;
     }
     IdxVec id_n = __builtin_nontemporal_load(idx4);
@@ -364,8 +362,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                         if (!seen) {
                             fg = ag; fh = ah; seen = true;
                         } else {  // head..head inside one lane: started in this span by construction
-                            a.gpart[close1 - 1] = ag;
-                            a.hpart[close1 - 1] = ah;
+                            a.part[close1 - 1] = make_float2(ag, ah);
                         }
                         ++close1;
                         ag = 0.f; ah = 0.f;
@@ -385,11 +382,9 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                 if (seen) {  // this lane's first head closes the segment of rank r1 - 1
                     const float tg = eg + fg, th = eh + fh;
                     if (r1 > rank_base) {  // it started inside this span: we own its slot
-                        a.gpart[r1 - 1] = tg;
-                        a.hpart[r1 - 1] = th;
+                        a.part[r1 - 1] = make_float2(tg, th);
                     } else {  // it started in an earlier span: this is the span's head carry
-                        a.carry_g[span] = tg;
-                        a.carry_h[span] = th;
+                        a.carry[span] = make_float2(tg, th);
                     }
                 }
                 // new open segment: everything after the tile's last head
@@ -416,11 +411,9 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         const float tg = open_spread ? wave_sum(og) : og, th = open_spread ? wave_sum(oh) : oh;
         if (lane == 0) {
             if (cur1 > rank_base) {  // the open segment's head lies in this span: we own its slot
-                a.gpart[cur1 - 1] = tg;
-                a.hpart[cur1 - 1] = th;
+                a.part[cur1 - 1] = make_float2(tg, th);
             } else {  // the whole span is interior to one segment
-                a.carry_g[span] = tg;
-                a.carry_h[span] = th;
+                a.carry[span] = make_float2(tg, th);
             }
         }
     }
@@ -609,63 +602,55 @@ __global__ __launch_bounds__(kBlock) void k_tile_combine(uint32_t nseg, uint32_t
 }
 
 // Adds, in span order, the carries that belong to the stored range [lo, hi).
-__device__ __forceinline__ void add_carries(uint32_t lo, uint32_t hi, uint32_t span_len,
-                                            const float* __restrict__ cg, const float* __restrict__ ch,
+__device__ __forceinline__ void add_carries(uint32_t lo, uint32_t hi, uint32_t span_len, const float2* __restrict__ carry,
                                             float& g, float& h) {
     uint32_t s = lo / span_len + 1;
     const uint32_t s_end = (hi - 1) / span_len;  // inclusive
     for (; s + 3 <= s_end; s += 4) {  // 4 independent loads in flight, sequential adds
-        const float g0 = cg[s], g1 = cg[s + 1], g2 = cg[s + 2], g3 = cg[s + 3];
-        const float h0 = ch[s], h1 = ch[s + 1], h2 = ch[s + 2], h3 = ch[s + 3];
-        g += g0; g += g1; g += g2; g += g3;
-        h += h0; h += h1; h += h2; h += h3;
+        const float2 c0 = carry[s], c1 = carry[s + 1], c2 = carry[s + 2], c3 = carry[s + 3];
+        g += c0.x; g += c1.x; g += c2.x; g += c3.x;
+        h += c0.y; h += c1.y; h += c2.y; h += c3.y;
     }
-    for (; s <= s_end; ++s) { g += cg[s]; h += ch[s]; }
+    for (; s <= s_end; ++s) { const float2 c = carry[s]; g += c.x; h += c.y; }
 }
 
 struct GatherPartsArgs {
     uint32_t nseg, npanels, span_len;
     const uint32_t* ptr_v;
-    const int32_t* rank_of_seg;
-    const float *gpart, *hpart, *cg, *ch;
+    const uint32_t* rank_code;  // [npanels*nseg] kNoRank for an empty virtual segment, else rank | kCarryBit
+    const float2* part;
+    const float2* carry;
 };
+constexpr uint32_t kNoRank = 0xFFFFFFFFu, kCarryBit = 0x80000000u;
 
 // (g, h) of real segment c over panels p0, p0 + stride, ...: each virtual segment = part + carries.
-// The lookups of one panel are a chain of dependent loads (rank -> part, pointers -> carries), so
-// they are issued for kBatch panels at a time: two memory round trips per batch instead of two per
-// panel.  The additions stay in panel order.
+// A lookup is rank -> part (two dependent loads; the carry bit says whether the segment runs into
+// later spans -- rare -- and only then are its pointers read), issued for kBatch panels at a time.
+// The additions stay in panel order.
 __device__ __forceinline__ void segment_sums(const GatherPartsArgs& a, uint32_t c, uint32_t p0, uint32_t stride,
                                              float& g, float& h) {
     constexpr int kBatch = 5;
     g = 0.f;
     h = 0.f;
     for (uint32_t pb = p0; pb < a.npanels; pb += stride * kBatch) {
-        int32_t r[kBatch];
-        uint32_t lo[kBatch], hi[kBatch];
+        uint32_t r[kBatch];
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
             const uint32_t p = pb + q * stride;
-            r[q] = -1;
-            lo[q] = hi[q] = 0;
-            if (p < a.npanels) {
-                const size_t v = (size_t) p * a.nseg + c;
-                r[q] = a.rank_of_seg[v];
-                lo[q] = a.ptr_v[v];
-                hi[q] = a.ptr_v[v + 1];
-            }
+            r[q] = p < a.npanels ? a.rank_code[(size_t) p * a.nseg + c] : kNoRank;
         }
-        float pg[kBatch], ph[kBatch];
+        float2 pp[kBatch];
+#pragma unroll
+        for (int q = 0; q < kBatch; ++q) pp[q] = r[q] != kNoRank ? a.part[r[q] & ~kCarryBit] : make_float2(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
-            pg[q] = r[q] >= 0 ? a.gpart[r[q]] : 0.f;
-            ph[q] = r[q] >= 0 ? a.hpart[r[q]] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-            if (r[q] >= 0) {
-                add_carries(lo[q], hi[q], a.span_len, a.cg, a.ch, pg[q], ph[q]);
-                g += pg[q];
-                h += ph[q];
+            if (r[q] != kNoRank) {
+                if (r[q] & kCarryBit) {
+                    const size_t v = (size_t) (pb + q * stride) * a.nseg + c;
+                    add_carries(a.ptr_v[v], a.ptr_v[v + 1], a.span_len, a.carry, pp[q].x, pp[q].y);
+                }
+                g += pp[q].x;
+                h += pp[q].y;
             }
         }
     }
@@ -719,15 +704,29 @@ struct FinKernelArgs {
 
 template <int PL>
 __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
+    // The lane that will own segment c is known up front: fetch what it needs at the very end (count,
+    // old pack entry, next vector entry) before the partial sums are chased, so that those loads do
+    // not queue up behind the rank -> part -> (barrier) chain.
+    constexpr int SEGS = kBlock / PL;
+    const bool flat = !a.gh_dense && !a.tile_part;
+    const uint32_t c0 = flat ? blockIdx.x * SEGS + threadIdx.x % SEGS : blockIdx.x * kBlock + threadIdx.x;
+    const bool owner = c0 < a.parts.nseg && (!flat || threadIdx.x / SEGS == 0);
+    uint32_t cnt = 0;
+    float2 old = make_float2(0.f, 0.f);
+    float next = 0.f;
+    if (owner) {
+        cnt = a.cnt_override ? a.cnt_override[c0] : a.seg_cnt[c0];
+        if (a.pack2) { old = a.pack2[c0]; next = a.next_vec[c0]; }
+    }
     uint32_t c;
     float g, h;
     if (a.gh_dense) {  // PL == 1 by construction
-        c = blockIdx.x * kBlock + threadIdx.x;
+        c = c0;
         if (c >= a.parts.nseg) return;
         g = a.gh_dense[c];
         h = a.gh_dense[a.parts.nseg + c];
     } else if (a.tile_part) {  // PL == 1: strips added in order
-        c = blockIdx.x * kBlock + threadIdx.x;
+        c = c0;
         if (c >= a.parts.nseg) return;
         g = 0.f; h = 0.f;
         for (uint32_t r = 0; r < a.tile_R; ++r) {
@@ -737,14 +736,13 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     } else if (!block_segment_sums<PL>(a.parts, c, g, h)) {
         return;
     }
-    const uint32_t cnt = a.cnt_override ? a.cnt_override[c] : a.seg_cnt[c];
     // reference: g / (lambda * |Omega| + sum u^2), 0 for an empty segment (src/CCD.cpp:6-16,112)
     const float x = cnt ? g / add_rn(mul_rn(a.lambda, (float) cnt), h) : 0.f;
     a.out_vec[c] = x;
     if (a.pack2) {
-        const float2 old = a.pack2[c];
         if (a.pack4) a.pack4[c] = make_float4(old.x, old.y, x, 0.f);
-        a.pack2[c] = make_float2(x, a.next_vec[c]);
+        // k = 1: the "next" rank is this one, so its old value is the x just written (out_vec aliases next_vec)
+        a.pack2[c] = make_float2(x, a.next_vec == a.out_vec ? x : next);
     }
 }
 
@@ -911,8 +909,8 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
     a.wg_panel = s.wg_panel; a.nspans = s.nspans;
     a.tiles_per_span = s.tiles_per_span; a.panel_rows = s.panel_rows; a.gather_len = s.gather_len; a.nne = s.nne;
     // cache panels: padding sits at every panel's end and gathers a zero, so no tile is masked by position
-    a.nnz = (s.panel_rows && !s.lds_panels) ? s.padded_nnz : s.nnz; a.gather = gather; a.perseg = perseg; a.gpart = s.gpart; a.hpart = s.hpart;
-    a.carry_g = s.carry_g; a.carry_h = s.carry_h; a.add = add;
+    a.nnz = (s.panel_rows && !s.lds_panels) ? s.padded_nnz : s.nnz; a.gather = gather; a.perseg = perseg; a.part = s.part;
+    a.carry = s.carry; a.add = add;
     switch (mode) {
         case FM_SWEEP: return launch_flat_mode<FM_SWEEP>(s, a, st);
         case FM_RESID: return launch_flat_mode<FM_RESID>(s, a, st);
@@ -943,7 +941,7 @@ int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float*
 static GatherPartsArgs parts_of(const SegStreamDev& s) {
     GatherPartsArgs g;
     g.nseg = s.nseg; g.npanels = s.npanels; g.span_len = s.tiles_per_span * kTileElems; g.ptr_v = s.ptr_v;
-    g.rank_of_seg = s.rank_of_seg; g.gpart = s.gpart; g.hpart = s.hpart; g.cg = s.carry_g; g.ch = s.carry_h;
+    g.rank_code = s.rank_code; g.part = s.part; g.carry = s.carry;
     return g;
 }
 

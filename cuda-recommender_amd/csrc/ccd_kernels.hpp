@@ -35,7 +35,7 @@ struct SegStreamDev {
     const uint32_t* flags32 = nullptr;         // [padded nnz / 32 + 16] head bits
     const uint32_t* hpre = nullptr;            // [padded nnz / 32 + 16] heads before each word
     uint32_t max_wg_ranks = 0;                 // most ranks any workgroup chunk touches
-    const int32_t* rank_of_seg = nullptr;      // [npanels*nseg]
+    const uint32_t* rank_code = nullptr;       // [npanels*nseg] 0xFFFFFFFF = empty, else rank | (bit 31: runs into later spans)
     const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id
     const uint32_t* wg_panel = nullptr;        // [nspans/spans_per_wg]
     const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding; nullptr: SegStreamStore::unpermute knows
@@ -47,10 +47,8 @@ struct SegStreamDev {
     const uint32_t* t_tile_sub = nullptr;      // [t_nB * t_nP + 1]
     float2* t_gh_part = nullptr;               // [t_R][t_stride] strip partials written by the tile kernel
     // reduction scratch written by the flat kernels
-    float* gpart = nullptr;    // [nne]
-    float* hpart = nullptr;    // [nne]
-    float* carry_g = nullptr;  // [nspans]
-    float* carry_h = nullptr;  // [nspans]
+    float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
+    float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run
 };
 
 enum FlatMode : int {

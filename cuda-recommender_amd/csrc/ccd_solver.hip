@@ -122,16 +122,29 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     MFX_TRY(flags32_.upload(L.flags32.data(), L.flags32.size(), MFX_HOST, st));
     MFX_TRY(hpre_.alloc(L.hpre.size()));
     MFX_TRY(hpre_.upload(L.hpre.data(), L.hpre.size(), MFX_HOST, st));
-    MFX_TRY(rank_of_seg_.alloc(nv));
-    MFX_TRY(rank_of_seg_.upload(L.rank_of_seg.data(), nv, MFX_HOST, st));
+    // rank per virtual segment + "runs into later spans" bit: the finalize then only reads a segment's
+    // pointers when it has carries to add (rare), 12 instead of 20 bytes per virtual segment
+    MFX_REQUIRE(L.nne < 0x80000000u, "too many virtual segments");
+    std::vector<uint32_t> rank_code(nv);
+    {
+        struct Ctx { uint32_t* dst; const int32_t* rank; const uint32_t* ptr_v; uint32_t span; } cx{rank_code.data(), L.rank_of_seg.data(), L.ptr_v.data(), L.span_len()};
+        parallel_ranges_u64(nv, [](uint64_t b, uint64_t e, void* p) {
+            Ctx& c = *static_cast<Ctx*>(p);
+            for (uint64_t v = b; v < e; ++v) {
+                if (c.rank[v] < 0) { c.dst[v] = 0xFFFFFFFFu; continue; }
+                const uint32_t lo = c.ptr_v[v], hi = c.ptr_v[v + 1];
+                c.dst[v] = (uint32_t) c.rank[v] | ((lo / c.span != (hi - 1) / c.span) ? 0x80000000u : 0u);
+            }
+        }, &cx);
+    }
+    MFX_TRY(rank_code_.alloc(nv ? nv : 1));
+    MFX_TRY(rank_code_.upload(rank_code.data(), nv, MFX_HOST, st));
     MFX_TRY(seg_of_rank_.alloc(L.nne ? L.nne : 1));
     MFX_TRY(seg_of_rank_.upload(L.seg_of_rank.data(), L.nne, MFX_HOST, st));
     MFX_TRY(wg_panel_.alloc(L.wg_panel.empty() ? 1 : L.wg_panel.size()));
     MFX_TRY(wg_panel_.upload(L.wg_panel.data(), L.wg_panel.size(), MFX_HOST, st));
-    MFX_TRY(gpart_.alloc_zero(L.nne ? L.nne : 1, st));
-    MFX_TRY(hpart_.alloc_zero(L.nne ? L.nne : 1, st));
-    MFX_TRY(carry_g_.alloc_zero(L.nspans, st));
-    MFX_TRY(carry_h_.alloc_zero(L.nspans, st));
+    MFX_TRY(part_.alloc_zero(L.nne ? L.nne : 1, st));
+    MFX_TRY(carry_.alloc_zero(L.nspans, st));
     // the host vectors behind the async uploads must outlive the copies
     MFX_HIP(hipStreamSynchronize(st));
     tm.lap("allocations + uploads");
@@ -142,10 +155,10 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     view.spans_per_wg = L.spans_per_wg; view.gather_len = G;
     view.ptr = ptr_.get(); view.ptr_v = ptr_v_.get(); view.seg_cnt = seg_cnt_.get(); view.idx = idx_.get();
     view.idx16 = idx16_.get();
-    view.val = val_.get(); view.flags32 = flags32_.get(); view.hpre = hpre_.get(); view.rank_of_seg = rank_of_seg_.get();
+    view.val = val_.get(); view.flags32 = flags32_.get(); view.hpre = hpre_.get(); view.rank_code = rank_code_.get();
     view.seg_of_rank = seg_of_rank_.get(); view.max_wg_ranks = L.max_wg_ranks;
-    view.wg_panel = wg_panel_.get(); view.perm = perm_.get(); view.gpart = gpart_.get(); view.hpart = hpart_.get();
-    view.carry_g = carry_g_.get(); view.carry_h = carry_h_.get();
+    view.wg_panel = wg_panel_.get(); view.perm = perm_.get(); view.part = part_.get();
+    view.carry = carry_.get();
     // the big host-side vectors are no longer needed
     for (auto* v : {&L.idx_local, &L.perm, &L.first_q}) { v->clear(); v->shrink_to_fit(); }
     L.idx16.clear(); L.idx16.shrink_to_fit();

@@ -28,8 +28,9 @@ public:
 private:
     FlatLayoutHost layout_;
     DevBuf<uint32_t> ptr_, ptr_v_, seg_cnt_, idx_, seg_of_rank_, flags32_, hpre_, wg_panel_, perm_;
-    DevBuf<float> val_, gpart_, hpart_, carry_g_, carry_h_;
-    DevBuf<int32_t> rank_of_seg_;
+    DevBuf<float> val_;
+    DevBuf<float2> part_, carry_;
+    DevBuf<uint32_t> rank_code_;
     DevBuf<uint16_t> idx16_;
     // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
     std::vector<uint32_t> first_q_host_, panel_end_host_;
