@@ -24,12 +24,6 @@ using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
 
-__device__ __forceinline__ float wave_sum_shfl(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
-}
-
 // Cross-lane moves on the VALU's DPP path (a few cycles) instead of ds_bpermute (an LDS round trip
 // per step): rows are 16 lanes; row_shr:n shifts inside a row, row_bcast15 / row_bcast31 carry
 // lane 15 / lane 31 into the following row(s), wave_shr:1 shifts the whole wavefront by one lane.
