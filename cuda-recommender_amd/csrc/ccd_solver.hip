@@ -417,6 +417,10 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         MFX_TRY(global_col_nnz_.alloc(n_));
         MFX_TRY(global_col_nnz_.upload(shard->global_col_nnz, n_, space, st_));
         global_test_nnz_ = shard->global_test_nnz;
+        // RCCL builds its rings / connections lazily, inside the first collective: take that hit here,
+        // in setup, with an all-reduce of the (still zero) column buffer, not inside the first iteration.
+        MFX_TRY(comm_allreduce_f32(comm_, gh_cols_.get(), (size_t) 2 * n_, st_));
+        MFX_HIP(hipStreamSynchronize(st_));
     }
     nnz_test_ = T ? T->nnz : 0;
     if (!comm_) global_test_nnz_ = nnz_test_;
