@@ -94,6 +94,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     tm.lap("build_flat_layout");
     FlatLayoutHost& L = layout_;
     MFX_REQUIRE(L.padded_nnz < 0xFFFFFF00ull, "padded non-zero count exceeds the 32-bit position range");
+    MFX_REQUIRE((uint64_t) L.npanels * nseg < 0x7FFFFFFFull, "panels x segments exceeds the 32-bit virtual-segment range");
 
     const size_t nv = (size_t) L.npanels * nseg;
     MFX_TRY(ptr_.alloc((size_t) nseg + 1));
