@@ -140,3 +140,37 @@ def test_bad_arguments_are_errors(mfx):
     bad.csc_row_idx[0] = 10 ** 6  # index out of range must be caught on the host, not fault on the GPU
     with pytest.raises(Exception):
         mfx.CcdSolver(bad, None, _p(mfx, 2))
+
+
+def _shuffle_within_segments(ptr, idx, val, rng):
+    idx, val = idx.copy(), val.copy()
+    for s in range(ptr.shape[0] - 1):
+        lo, hi = int(ptr[s]), int(ptr[s + 1])
+        if hi - lo > 1:
+            o = rng.permutation(hi - lo)
+            idx[lo:hi] = idx[lo:hi][o]
+            val[lo:hi] = val[lo:hi][o]
+    return idx, val
+
+
+@pytest.mark.parametrize("kw", [{"panel_rows": 64}, {"panel_rows": -64}, {"panel_rows": -1}, {"tile": (40 << 16) | 30}])
+def test_unsorted_indices_inside_segments(mfx, orc, kw):
+    """Entries of a row / column in arbitrary order (the reference's loader does not sort either): a
+    panel is then visited several times per segment, so the layout must keep its full provenance array
+    (no run compression) -- factors, test RMSE and both residual copies as the oracle's on the SAME order."""
+    d = mfx.dataset.synth_ratings(700, 500, 30000, seed=77, skew=0.7, test_frac=0.02).copy()
+    rng = np.random.default_rng(5)
+    d.csr_col_idx, d.csr_val = _shuffle_within_segments(d.csr_row_ptr, d.csr_col_idx, d.csr_val, rng)
+    d.csc_row_idx, d.csc_val = _shuffle_within_segments(d.csc_col_ptr, d.csc_row_idx, d.csc_val, rng)
+    W0 = mfx.initial_col(5, d.rows)
+    Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, 5, 0.05, 3, 2, 2)
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 5, 3, 2, **kw))
+    s.set_factors(W0.copy())
+    rep = s.iterate(3)
+    W, H = s.get_factors()
+    csc, csr = s.get_residual(d.nnz)
+    s.close()
+    scale = max(float(np.abs(Wr).max()), float(np.abs(Hr).max()))
+    assert np.max(np.abs(W - Wr)) < 2e-3 * scale and np.max(np.abs(H - Hr)) < 2e-3 * scale
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-4)
+    assert np.max(np.abs(csc - csc_ref)) < 1e-3 and np.max(np.abs(csr - csr_ref)) < 1e-3
