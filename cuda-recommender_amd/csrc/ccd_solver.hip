@@ -246,7 +246,7 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     // k = 40: 0.86 ms per outer iteration plain vs 1.57 ms with panels; ML-10M shape: panels win 1.65x).
     if (p.panel_rows == 0 && nnz < 4000000ull) return o;
     // 64 KB of LDS per workgroup (two 1024-thread workgroups per CU): 8 KB for the staged per-segment
-    // operands, 56 KB for the slice.  Measured on the Netflix shape (tools/sweep_r01_j.sh): slices of
+    // operands, 56 KB for the slice.  Measured on the Netflix shape (round-1 sweep with a temporary env knob): slices of
     // 40/48/56/64/72 KB give 30.1/29.9/28.0/29.1/28.4 ms per outer iteration.
     constexpr uint32_t slice_kb = 56;
     uint32_t pr = p.panel_rows > 0 ? (uint32_t) p.panel_rows : (slice_kb * 1024u) / elem_bytes - 1;
