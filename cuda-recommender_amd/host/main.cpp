@@ -1,7 +1,11 @@
-// main.cpp -- mfx_train: the reference's driver flow (reference: src/main.cpp:38-173) on top of
-// libmfx.  Same flags, same log lines, same validation calls; the GPU path is this repository's
-// HIP implementation behind kernel_wrapper_{ccdpp,als}_NV.  The reference's -OMP leg (its CPU
-// solver) is not part of the product: the CPU restatement lives under oracle/ as a test oracle.
+// main.cpp -- mfx_train, the command-line driver over libmfx.
+//
+// Speaks the reference driver's protocol (reference: src/main.cpp:38-173): the same flags, the same
+// log lines in the same order, the same post-run checks -- so that scripts written against the
+// reference (scripts/times.sh and friends) keep working -- with the GPU leg served by this repository's
+// HIP implementation behind kernel_wrapper_{ccdpp,als}_NV.  Two steps the reference only stubs out are
+// real here: -save <file> (model dump) and -predict (file-based scoring).  The reference's -OMP leg,
+// its CPU solver, is not part of the product; the CPU restatement lives under oracle/ as a test oracle.
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -10,91 +14,114 @@
 #include "reference_api.hpp"
 #include "tools.hpp"
 
-static void runCUDA(SparseMatrix& R, TestData& T, MatData& W, MatData& H, parameter& parameters, bool ALS) {
-    if (ALS) kernel_wrapper_als_NV(R, T, W, H, parameters);
-    else if (parameters.n_gpus > 1) kernel_wrapper_ccdpp_multi(R, T, W, H, parameters, parameters.n_gpus);
-    else kernel_wrapper_ccdpp_NV(R, T, W, H, parameters);
+namespace {
+
+struct Stopwatch {
+    std::chrono::high_resolution_clock::time_point origin = std::chrono::high_resolution_clock::now();
+    double seconds() const { return std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - origin).count(); }
+};
+
+void rule() { puts("------------------------------------------------------------"); }
+
+// Factor pair in the solver's layout: CCD++ keeps k rows of length rows/cols, ALS rows/cols rows of
+// length k; both start from the reference's initial_col stream.
+struct Factors {
+    MatData W, H;
+    Factors(bool als, unsigned k, long rows, long cols) {
+        if (als) { initial_col(W, rows, k); initial_col(H, cols, k); }
+        else { initial_col(W, k, rows); initial_col(H, k, cols); }
+    }
+};
+
+void solve_on_gpu(SparseMatrix& R, TestData& T, Factors& f, parameter& prm, bool als) {
+    if (als) kernel_wrapper_als_NV(R, T, f.W, f.H, prm);
+    else if (prm.n_gpus > 1) kernel_wrapper_ccdpp_multi(R, T, f.W, f.H, prm, prm.n_gpus);
+    else kernel_wrapper_ccdpp_NV(R, T, f.W, f.H, prm);
 }
 
-// mfx_train -predict <model> <test.txt> <output>: the file-based scoring step the reference stubs
-// out (src/main.cpp:146-149); the model must have been written row-major (rows x k), i.e. by an
-// ALS run with -save, or converted.
-static int predict_mode(int argc, char** argv) {
+// -predict <model> <test.txt> <output>: file-based scoring; the model must be row-major (rows x k),
+// i.e. written by an ALS run with -save, or converted.
+int predict_from_files(int argc, char** argv) {
     if (argc != 5) { fprintf(stderr, "usage: mfx_train -predict model_file test_file output_file\n"); return EXIT_FAILURE; }
-    FILE* model = fopen(argv[2], "rb");
-    FILE* test = fopen(argv[3], "r");
-    if (!model) { fprintf(stderr, "can't open model file %s\n", argv[2]); return EXIT_FAILURE; }
-    if (!test) { fprintf(stderr, "can't open test file %s\n", argv[3]); return EXIT_FAILURE; }
-    FILE* out = fopen(argv[4], "w");
-    if (!out) { fprintf(stderr, "can't open output file %s\n", argv[4]); return EXIT_FAILURE; }
-    calculate_rmse_from_file(model, test, out);
-    fclose(model); fclose(test); fclose(out);
+    const char* names[3] = {argv[2], argv[3], argv[4]};
+    const char* modes[3] = {"rb", "r", "w"};
+    const char* what[3] = {"model", "test", "output"};
+    FILE* fp[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3; ++i) {
+        fp[i] = fopen(names[i], modes[i]);
+        if (!fp[i]) {
+            fprintf(stderr, "can't open %s file %s\n", what[i], names[i]);
+            for (int j = 0; j < i; ++j) fclose(fp[j]);
+            return EXIT_FAILURE;
+        }
+    }
+    calculate_rmse_from_file(fp[0], fp[1], fp[2]);
+    for (FILE* f : fp) fclose(f);
     return EXIT_SUCCESS;
 }
 
-int main(int argc, char* argv[]) {
-    if (argc > 1 && !strcmp(argv[1], "-predict")) return predict_mode(argc, argv);
-    auto t_start = std::chrono::high_resolution_clock::now();
-    parameter param = parse_command_line(argc, argv);
-    const char* save_path = nullptr;
+const char* option_value(int argc, char** argv, const char* flag) {
     for (int i = 1; i + 1 < argc; ++i)
-        if (!strcmp(argv[i], "-save")) save_path = argv[i + 1];
+        if (!strcmp(argv[i], flag)) return argv[i + 1];
+    return nullptr;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    if (argc > 1 && !strcmp(argv[1], "-predict")) return predict_from_files(argc, argv);
+    const Stopwatch whole_run;
+    parameter prm = parse_command_line(argc, argv);
+    const char* model_path = option_value(argc, argv, "-save");
 
     SparseMatrix R;
     TestData T;
-    puts("------------------------------------------------------------");
+    rule();
     puts("[info] Loading R matrix...");
-    auto t0 = std::chrono::high_resolution_clock::now();
-    load(param.src_dir, R, T);
-    auto t1 = std::chrono::high_resolution_clock::now();
-    printf("[info] Loading rating data time: %lf s.\n", std::chrono::duration<double>(t1 - t0).count());
-    puts("------------------------------------------------------------");
-
-    const bool ifALS = param.solver_type == solvertype::ALS;
-    puts(ifALS ? "[info] Picked Version: ALS!" : "[info] Picked Version: CCD!");
-    MatData W_cuda, H_cuda, W_ref, H_ref;
-    if (ifALS) {
-        initial_col(W_cuda, R.rows, param.k); initial_col(H_cuda, R.cols, param.k);
-        initial_col(W_ref, R.rows, param.k);  initial_col(H_ref, R.cols, param.k);
-    } else {
-        initial_col(W_cuda, param.k, R.rows); initial_col(H_cuda, param.k, R.cols);
-        initial_col(W_ref, param.k, R.rows);  initial_col(H_ref, param.k, R.cols);
+    {
+        const Stopwatch sw;
+        load(prm.src_dir, R, T);
+        printf("[info] Loading rating data time: %lf s.\n", sw.seconds());
     }
+    rule();
+
+    const bool als = prm.solver_type == solvertype::ALS;
+    puts(als ? "[info] Picked Version: ALS!" : "[info] Picked Version: CCD!");
+    Factors solved(als, prm.k, R.rows, R.cols), untouched(als, prm.k, R.rows, R.cols);
     printf("[info] ThreadsPerBlock = %u | Blocks = %u | K = %u | InnerIter = %d | OuterIter = %d | Threads = %d | L = %.3f\n",
-           param.nThreadsPerBlock, param.nBlocks, param.k, param.maxinneriter, param.maxiter, param.threads, param.lambda);
+           prm.nThreadsPerBlock, prm.nBlocks, prm.k, prm.maxinneriter, prm.maxiter, prm.threads, prm.lambda);
 
-    if (param.enable_cuda) {
-        puts("------------------------------------------------------------");
+    if (prm.enable_cuda) {
+        rule();
         puts("[INFO] Computing with CUDA...");
-        auto t5 = std::chrono::high_resolution_clock::now();
-        runCUDA(R, T, W_cuda, H_cuda, param, ifALS);
-        auto t6 = std::chrono::high_resolution_clock::now();
-        printf("[info] CUDA Training time: %lf s.\n", std::chrono::duration<double>(t6 - t5).count());
-        puts("------------------------------------------------------------");
-        calculate_rmse_directly(W_cuda, H_cuda, T, param.k, ifALS);
+        const Stopwatch sw;
+        solve_on_gpu(R, T, solved, prm, als);
+        printf("[info] CUDA Training time: %lf s.\n", sw.seconds());
+        rule();
+        calculate_rmse_directly(solved.W, solved.H, T, prm.k, als);
     }
-    if (param.enable_omp) {
-        puts("------------------------------------------------------------");
+    if (prm.enable_omp) {
+        rule();
         puts("[info] -OMP: the CPU solver is not built into mfx_train (it exists as the test oracle under oracle/).");
     }
+
+    // The reference compares against the factors of its -OMP leg; without one they are still the
+    // initial values, and -- exactly like the reference run with -CUDA only -- the check reports that.
     std::cout << "[info] validate the results." << std::endl;
-    if (ifALS) {
-        golden_compare(W_cuda, W_ref, R.rows, param.k);
-        golden_compare(H_cuda, H_ref, R.cols, param.k);
-    } else {
-        golden_compare(W_cuda, W_ref, param.k, R.rows);
-        golden_compare(H_cuda, H_ref, param.k, R.cols);
-    }
-    if (save_path) {  // the step the reference stubs out (src/main.cpp:146-147)
-        FILE* fp = fopen(save_path, "wb");
-        if (!fp) { fprintf(stderr, "can't open model file %s\n", save_path); return EXIT_FAILURE; }
-        save_mat_t(W_cuda, fp, ifALS);
-        save_mat_t(H_cuda, fp, ifALS);
+    const long w_outer = als ? R.rows : (long) prm.k, w_inner = als ? (long) prm.k : R.rows;
+    const long h_outer = als ? R.cols : (long) prm.k, h_inner = als ? (long) prm.k : R.cols;
+    golden_compare(solved.W, untouched.W, w_outer, w_inner);
+    golden_compare(solved.H, untouched.H, h_outer, h_inner);
+
+    if (model_path) {
+        FILE* fp = fopen(model_path, "wb");
+        if (!fp) { fprintf(stderr, "can't open model file %s\n", model_path); return EXIT_FAILURE; }
+        save_mat_t(solved.W, fp, als);
+        save_mat_t(solved.H, fp, als);
         fclose(fp);
-        printf("[info] model written to %s\n", save_path);
+        printf("[info] model written to %s\n", model_path);
     }
-    puts("------------------------------------------------------------");
-    auto t_end = std::chrono::high_resolution_clock::now();
-    std::cout << "Total Time: " << std::chrono::duration<double>(t_end - t_start).count() << " s.\n";
+    rule();
+    std::cout << "Total Time: " << whole_run.seconds() << " s.\n";
     return EXIT_SUCCESS;
 }
