@@ -125,3 +125,49 @@ def test_fullsize_als_normal_equations(big):
     cols = np.concatenate([rng.choice(COLS, 150, replace=False), [int(np.argmax(np.diff(host.csc_col_ptr.astype(np.int64))))]])
     assert check(host.csr_row_ptr, host.csr_col_idx, host.csr_val, H0, W, rows) < 2e-3      # W solved against H0
     assert check(host.csc_col_ptr, host.csc_row_idx, host.csc_val, W, H, cols) < 2e-3       # H solved against that W
+
+
+def test_fullsize_follows_the_float64_trajectory(big):
+    """The whole solve against the SAME algorithm in float64 (torch on the device, used as a calculator):
+    test RMSE per outer iteration within 2e-5, factors within 1e-3 of scale after 2 outer iterations at
+    k = 8.  (The fp32 CPU reference itself is 5e-5 ... 2e-4 away from float64 at this size: its sequential
+    fp32 sums over columns with up to 10^6 ratings -- tools/rmse_fullsize_check.py)"""
+    mfx, torch, d = big
+    k, lam, iters = 8, 0.05, 2
+    dev = torch.device("cuda:0")
+    f8 = torch.float64
+    W0 = mfx.initial_col(k, ROWS)
+    p = mfx.parameter()
+    p.k, p.lambda_ = k, lam
+    s = mfx.CcdSolver(None, None, p, device_arrays=d)
+    s.set_factors(W0)
+    rep = s.iterate(iters)
+    Wg, Hg = s.get_factors()
+    s.close()
+
+    rows = torch.repeat_interleave(torch.arange(ROWS, device=dev), (d["csr_row_ptr"][1:] - d["csr_row_ptr"][:-1]).long())
+    cols = d["csr_col_idx"].long()
+    r = d["csr_val"].to(f8)
+    cnt_r, cnt_c = torch.bincount(rows, minlength=ROWS).to(f8), torch.bincount(cols, minlength=COLS).to(f8)
+    W, H = torch.from_numpy(W0).to(dev).to(f8), torch.zeros((k, COLS), dtype=f8, device=dev)
+    tr, tc, tv = d["test_row"].long(), d["test_col"].long(), d["test_val"].to(f8)
+    rmse64 = []
+    for it in range(iters):
+        for t in range(k):
+            u, v = W[t], H[t]
+            if it > 0:
+                r += u[rows] * v[cols]
+            ur = u[rows]
+            g, h = torch.bincount(cols, weights=ur * r, minlength=COLS), torch.bincount(cols, weights=ur * ur, minlength=COLS)
+            v = torch.where(cnt_c > 0, g / (lam * cnt_c + h + (cnt_c == 0)), torch.zeros_like(g))
+            vc = v[cols]
+            g, h = torch.bincount(rows, weights=vc * r, minlength=ROWS), torch.bincount(rows, weights=vc * vc, minlength=ROWS)
+            u = torch.where(cnt_r > 0, g / (lam * cnt_r + h + (cnt_r == 0)), torch.zeros_like(g))
+            r -= u[rows] * vc
+            W[t], H[t] = u, v
+        rmse64.append(float(torch.sqrt((((W[:, tr] * H[:, tc]).sum(0) - tv) ** 2).mean())))
+    rm = np.array([x.rmse for x in rep])
+    assert np.all(np.abs(rm - np.array(rmse64)) < 2e-5), (rm, rmse64)
+    scale = float(max(W.abs().max(), H.abs().max()))
+    assert float((torch.from_numpy(Wg).to(dev).to(f8) - W).abs().max()) < 1e-3 * scale
+    assert float((torch.from_numpy(Hg).to(dev).to(f8) - H).abs().max()) < 1e-3 * scale
