@@ -284,7 +284,7 @@ def main() -> None:
     if rank == 0:
         out = {
             "metric": "rating-nnz/sec per CCD++ outer iter at k=64", "value": round(value, 1), "unit": "nnz/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 6),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Netflix-shaped synthetic (BASELINE configs[2]): per-GPU "
                                    f"{a.rows}x{a.cols}, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam}",

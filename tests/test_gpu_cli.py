@@ -90,7 +90,10 @@ def test_bench_contract_line():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "nnz/s" and d["vs_baseline"] is None
-    assert abs(d["value"] - 5000000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    # value and ms_per_step are two roundings of one measurement (value to 0.1 nnz/s, ms_per_step to 1e-6 ms):
+    # consistency only, no assertion on how long anything took
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / d["config"]["nnz_global"] - 1.0) < 1e-4
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["rank_one_kernel"]["kernel"] == "ccd_flat_sweep" and d["rank_one_kernel"]["launches"] == 16
