@@ -97,7 +97,7 @@ def main() -> None:
     ap.add_argument("--tiles", type=int, default=0)
     ap.add_argument("--panel-rows", type=int, default=0, help="LDS panel size (0 auto, -1 off)")
     ap.add_argument("--wg-waves", type=int, default=0, help="waves per workgroup of the panel kernel (0 = 16)")
-    ap.add_argument("--tile", type=int, default=0, help="2-D tile order: 0 auto, -1 off, >0 (slice << 16) | block")
+    ap.add_argument("--layout-build", type=int, default=0, help="0 auto (GPU when possible), 1 host, 2 GPU or fail")
     ap.add_argument("--graph", type=int, default=0, help="0 = hipGraph replay of outer iterations, -1 = eager launches")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--force-comm", action="store_true",
@@ -155,7 +155,7 @@ def main() -> None:
     p = mfx.parameter()
     p.k, p.lambda_, p.maxinneriter, p.device = a.k, a.lam, a.inner, local_rank
     p.schedule, p.kernel_variant, p.tiles_per_span = a.schedule, a.variant, a.tiles
-    p.panel_rows, p.wg_waves, p.graph, p.tile = a.panel_rows, a.wg_waves, a.graph, a.tile
+    p.panel_rows, p.wg_waves, p.graph, p.layout_build = a.panel_rows, a.wg_waves, a.graph, a.layout_build
     t0 = time.time()
     solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt if comm else None,
                            global_test_nnz=ntest_global, device_arrays=d)
@@ -250,7 +250,7 @@ def main() -> None:
         p2 = mfx.parameter()
         p2.k, p2.lambda_, p2.maxinneriter, p2.device = a.k, a.lam, 2, local_rank
         p2.schedule, p2.kernel_variant, p2.tiles_per_span = a.schedule, a.variant, a.tiles
-        p2.panel_rows, p2.wg_waves, p2.graph, p2.tile, p2.profile = a.panel_rows, a.wg_waves, -1, a.tile, 1
+        p2.panel_rows, p2.wg_waves, p2.graph, p2.layout_build, p2.profile = a.panel_rows, a.wg_waves, -1, a.layout_build, 1
         s2 = mfx.CcdSolver(None, None, p2, device_arrays=d)
         s2.set_factors(W0)
         s2.iterate(1, with_rmse=False)

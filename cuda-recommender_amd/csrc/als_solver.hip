@@ -548,12 +548,12 @@ int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipS
     AlsArgs a = base;
     if (nitems) {
         a.count = nitems;
-        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_gram16, dim3(nitems), dim3(64), lds_bytes, st, a);
+        hipLaunchKernelGGL(k_als_gram16, dim3(nitems), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     if (nreduces) {
         a.count = nreduces;
-        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_reduce16, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        hipLaunchKernelGGL(k_als_reduce16, dim3(nreduces), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     return MFX_OK;
@@ -564,23 +564,21 @@ int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipS
     constexpr int KP = 32 * NT;
     // packed lower triangle (rows rounded up to 4 floats) + rhs: see solve_tail
     const size_t lds_bytes = ((size_t) 4 * (KP / 4 + 1) * (2 * (KP / 4)) + KP) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds_bytes > 48 * 1024) {
+    if (lds_bytes > 48 * 1024) {  // a per-device attribute; setting it again is cheap next to a half-sweep
         MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_gram<NT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
         MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_reduce<NT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-        attr_set = true;
     }
     AlsArgs a = base;
     if (nitems) {
         a.count = nitems;
-        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_gram<NT>, dim3(nitems), dim3(64), lds_bytes, st, a);
+        hipLaunchKernelGGL(k_als_gram<NT>, dim3(nitems), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     if (nreduces) {
         a.count = nreduces;
-        MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_als_reduce<NT>, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        hipLaunchKernelGGL(k_als_reduce<NT>, dim3(nreduces), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     return MFX_OK;
@@ -607,8 +605,9 @@ size_t als_ws_floats(uint32_t nslots, uint32_t k) {
     return (size_t) nslots * (nt * (nt + 1) / 2 * 1024 + nt * 64);
 }
 
-int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, const uint32_t* ptr_in, const uint32_t* idx_in,
+int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, uint32_t G, const uint32_t* ptr_in, const uint32_t* idx_in,
                    const float* val_in, mfx_memspace space, uint32_t chunk, hipStream_t st) {
+    MFX_REQUIRE(nnz_ == 0 || (idx_in && val_in), "null index / value array with %llu non-zeros", (unsigned long long) nnz_);
     nseg = nseg_;
     nnz = nnz_;
     std::vector<uint32_t> hp((size_t) nseg + 1);
@@ -641,6 +640,8 @@ int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, const uint32_t* ptr_in, const 
     MFX_TRY(items.alloc(nitems ? nitems : 1)); MFX_TRY(items.upload(it.data(), nitems, MFX_HOST, st));
     MFX_TRY(reduces.alloc(nreduces ? nreduces : 1)); MFX_TRY(reduces.upload(rd.data(), nreduces, MFX_HOST, st));
     MFX_HIP(hipStreamSynchronize(st));
+    // the Gramian kernels use idx[q] as a row of X without further checks
+    MFX_TRY(check_index_range(idx.get(), nnz, G, "ALS gather index", st));
     return MFX_OK;
 }
 
@@ -721,8 +722,8 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         MFX_REQUIRE(row_bounds_.back() == R->rows && col_bounds_.back() == R->cols, "ALS shards do not cover the matrix");
     }
     // W-half walks CSR rows with csr_val (src/ALS.cpp:132), H-half walks CSC columns
-    MFX_TRY(rows_.build(lrows, nnz_rows, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, kAlsChunk, st_));
-    MFX_TRY(cols_.build(lcols, nnz_cols, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, kAlsChunk, st_));
+    MFX_TRY(rows_.build(lrows, nnz_rows, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, kAlsChunk, st_));
+    MFX_TRY(cols_.build(lcols, nnz_cols, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, kAlsChunk, st_));
     // one extra, all-zero row each: the Gramian kernel gathers it for positions past a segment's end
     MFX_TRY(W_.alloc_zero(((size_t) m_ + 1) * k_, st_));
     MFX_TRY(H_.alloc_zero(((size_t) n_ + 1) * k_, st_));
@@ -735,6 +736,8 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         MFX_TRY(t_row_.alloc(nnz_test_)); MFX_TRY(t_row_.upload(T->row, nnz_test_, space, st_));
         MFX_TRY(t_col_.alloc(nnz_test_)); MFX_TRY(t_col_.upload(T->col, nnz_test_, space, st_));
         MFX_TRY(t_val_.alloc(nnz_test_)); MFX_TRY(t_val_.upload(T->val, nnz_test_, space, st_));
+        MFX_TRY(check_index_range(t_row_.get(), (uint64_t) nnz_test_, m_, "test-set row", st_));
+        MFX_TRY(check_index_range(t_col_.get(), (uint64_t) nnz_test_, n_, "test-set column", st_));
     }
     MFX_TRY(rmse_partials_.alloc_zero(kRmseBlocks, st_));
     MFX_TRY(rmse_sum_.alloc_zero(1, st_));
@@ -858,6 +861,7 @@ int als_gramian_op(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const floa
     MFX_HIP(hipStreamCreateWithFlags(&os.st, hipStreamNonBlocking));
     DevBuf<uint32_t> didx, fail_cnt; DevBuf<float> dval, dX, dY, dA; DevBuf<AlsItem> ditem;
     MFX_TRY(didx.alloc(cnt)); MFX_TRY(didx.upload(idx, cnt, MFX_HOST, os.st));
+    MFX_TRY(check_index_range(didx.get(), (uint64_t) cnt, (uint32_t) nrows_x, "ALS gather index", os.st));
     MFX_TRY(dval.alloc_zero(cnt, os.st));
     MFX_TRY(dX.alloc_zero(((size_t) nrows_x + 1) * k, os.st)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
     MFX_TRY(dY.alloc_zero(k, os.st)); MFX_TRY(dA.alloc_zero((size_t) k * k, os.st));
@@ -880,7 +884,7 @@ int als_half_op(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* 
     OpStream os;
     MFX_HIP(hipStreamCreateWithFlags(&os.st, hipStreamNonBlocking));
     AlsHalf h;
-    MFX_TRY(h.build((uint32_t) nseg, (uint64_t) nnz, ptr, idx, val, MFX_HOST, kAlsChunk, os.st));
+    MFX_TRY(h.build((uint32_t) nseg, (uint64_t) nnz, (uint32_t) nrows_x, ptr, idx, val, MFX_HOST, kAlsChunk, os.st));
     DevBuf<float> dX, dY, ws; DevBuf<uint32_t> fail_cnt;
     MFX_TRY(dX.alloc_zero(((size_t) nrows_x + 1) * k, os.st)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
     MFX_TRY(dY.alloc_zero((size_t) nseg * k, os.st));

@@ -30,7 +30,8 @@ struct AlsHalf {
     DevBuf<AlsItem> items;
     DevBuf<AlsReduce> reduces;
     uint32_t nitems = 0, nreduces = 0, nslots = 0;
-    int build(uint32_t nseg, uint64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
+    // G = number of factor rows the indices address: every idx must be < G (checked on the device)
+    int build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx, const float* val,
               mfx_memspace space, uint32_t chunk, hipStream_t st);
 };
 

@@ -8,7 +8,7 @@
 #include "ccd_kernels.hpp"
 
 #include <algorithm>
-
+#include <mutex>
 #include <type_traits>
 
 #include "flat_layout.hpp"
@@ -414,187 +414,6 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Variant 2: 2-D tile kernel (tile_layout.hpp) for hyper-sparse orientations.  One 1024-thread
-// workgroup per (segment block, strip): the block's per-segment operands and (g, h) accumulators
-// stay in LDS for the whole pass; the gathered operand arrives one slice at a time (double
-// buffered through registers: the global loads of slice p+1 are in flight while tile p is
-// processed).  A wavefront takes the sub-tiles j = first + wave, + 16, ... of each tile; lane l owns
-// slots 2l, 2l+1.  Runs never cross a sub-tile, so every (tile, segment) pair is closed by exactly
-// one lane: plain LDS read-modify-write, fixed order (tiles in panel order, strips in the finalize).
-// ---------------------------------------------------------------------------------------------
-struct TileArgs {
-    const uint32_t* code;
-    float* val;
-    const uint32_t* tile_sub;
-    uint32_t nseg, gather_len, QB, SR, nP, R, part_stride;
-    const void* gather;
-    const void* perseg;
-    float2* gh_part;
-    int add;
-};
-
-constexpr int kTileBlock = 1024;
-constexpr int kTileStage = 5;  // slice entries staged per thread: SR <= kTileStage * kTileBlock
-constexpr uint32_t kNoSub = 0xFFFFFFFFu;
-using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-
-__host__ __device__ constexpr size_t align16(size_t x) { return (x + 15) / 16 * 16; }
-
-template <int MODE>
-struct TileLds {
-    using TR = ModeTraits<MODE>;
-    static __host__ __device__ size_t perseg_bytes(uint32_t QB) { return TR::kPerSeg ? align16(((size_t) QB + 1) * sizeof(typename TR::P)) : 0; }
-    static __host__ __device__ size_t acc_bytes(uint32_t QB) { return TR::kDot ? align16(((size_t) QB + 1) * sizeof(float2)) : 0; }
-    static __host__ __device__ size_t slice_bytes(uint32_t SR) { return align16(((size_t) SR + 1) * sizeof(typename TR::G)); }
-    static __host__ __device__ size_t total(uint32_t QB, uint32_t SR) { return perseg_bytes(QB) + acc_bytes(QB) + 2 * slice_bytes(SR); }
-};
-
-__device__ __forceinline__ uint32_t dpp_prev_lane(uint32_t x) {  // lane l <- lane l-1 (lane 0 <- 0)
-    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, kDppWaveShr1, 0xF, 0xF, true);
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kTileBlock) void k_tile(TileArgs a) {
-    using TR = ModeTraits<MODE>;
-    using G = typename TR::G;
-    using P = typename TR::P;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    P* __restrict__ Bl = reinterpret_cast<P*>(lds_raw);
-    float2* __restrict__ ghl = reinterpret_cast<float2*>(lds_raw + TileLds<MODE>::perseg_bytes(a.QB));
-    G* const sl0 = reinterpret_cast<G*>(lds_raw + TileLds<MODE>::perseg_bytes(a.QB) + TileLds<MODE>::acc_bytes(a.QB));
-    G* const sl1 = reinterpret_cast<G*>(reinterpret_cast<unsigned char*>(sl0) + TileLds<MODE>::slice_bytes(a.SR));
-    const G* __restrict__ gather = static_cast<const G*>(a.gather);
-    const P* __restrict__ perseg = static_cast<const P*>(a.perseg);
-    const uint32_t b = blockIdx.x / a.R, r = blockIdx.x - b * a.R;
-    const uint32_t seg0 = b * a.QB;
-    const uint32_t nsl = a.nseg - seg0 < a.QB ? a.nseg - seg0 : a.QB;
-    if constexpr (TR::kPerSeg) {
-        for (uint32_t i = tid; i < nsl; i += kTileBlock) Bl[i] = perseg[seg0 + i];
-        if (tid == 0) Bl[a.QB] = zero_of(P{});  // padding slots point here
-    }
-    if constexpr (TR::kDot)
-        for (uint32_t i = tid; i <= a.QB; i += kTileBlock) ghl[i] = make_float2(0.f, 0.f);
-    const uint32_t p_lo = (uint32_t) ((uint64_t) r * a.nP / a.R), p_hi = (uint32_t) ((uint64_t) (r + 1) * a.nP / a.R);
-
-    G stage[kTileStage];
-    auto load_stage = [&](uint32_t p) {
-        const uint32_t gbase = p * a.SR;
-        const uint32_t cnt = a.gather_len - gbase < a.SR ? a.gather_len - gbase : a.SR;
-#pragma unroll
-        for (int j = 0; j < kTileStage; ++j) {
-            const uint32_t i = tid + j * kTileBlock;
-            stage[j] = i < cnt ? gather[gbase + i] : zero_of(G{});
-        }
-    };
-    auto store_stage = [&](G* dst) {
-#pragma unroll
-        for (int j = 0; j < kTileStage; ++j) {
-            const uint32_t i = tid + j * kTileBlock;
-            if (i < a.SR) dst[i] = stage[j];
-        }
-        if (tid == 0) dst[a.SR] = zero_of(G{});  // padding slots point here
-    };
-
-    const u32x2* __restrict__ code2 = reinterpret_cast<const u32x2*>(a.code) + lane;
-    f32x2* __restrict__ val2 = reinterpret_cast<f32x2*>(a.val) + lane;
-    u32x2 c_n{};
-    f32x2 v_n{};
-    uint32_t j_n = kNoSub;  // sub-tile held in (c_n, v_n); wave-uniform
-    auto issue = [&](uint32_t j) {
-        c_n = __builtin_nontemporal_load(code2 + (size_t) j * 64);
-        v_n = __builtin_nontemporal_load(val2 + (size_t) j * 64);
-        j_n = j;
-    };
-
-    if (p_lo < p_hi) {
-        load_stage(p_lo);
-        const size_t t0 = (size_t) b * a.nP + p_lo;
-        const uint32_t f0 = a.tile_sub[t0] + wave;
-        if (f0 < a.tile_sub[t0 + 1]) issue(f0);
-        store_stage(sl0);
-    }
-    __syncthreads();
-
-    for (uint32_t p = p_lo; p < p_hi; ++p) {
-        const G* __restrict__ cur = ((p - p_lo) & 1) ? sl1 : sl0;
-        G* const nxt = ((p - p_lo) & 1) ? sl0 : sl1;
-        const bool more = p + 1 < p_hi;
-        const size_t t = (size_t) b * a.nP + p;
-        const uint32_t s_end = a.tile_sub[t + 1];
-        const uint32_t nx_first = more ? s_end + wave : kNoSub;          // this wave's first sub-tile of tile p+1 ...
-        const bool nx_ok = more && nx_first < a.tile_sub[t + 2];         // ... if that tile has one for it
-        if (more) load_stage(p + 1);
-        uint32_t j = a.tile_sub[t] + wave;
-        if (j < s_end && j_n != j) issue(j);  // not prefetched (the wave had nothing to do in the previous tile)
-        while (j < s_end) {
-            const u32x2 c = c_n;
-            const f32x2 v = v_n;
-            j_n = kNoSub;
-            if (j + 16 < s_end) issue(j + 16);
-            else if (nx_ok) issue(nx_first);
-            const uint32_t S0 = c.x >> 16, S1 = c.y >> 16;
-            const G ga0 = cur[c.x & 0xFFFFu], ga1 = cur[c.y & 0xFFFFu];
-            P ps0{}, ps1{};
-            if constexpr (TR::kPerSeg) { ps0 = Bl[S0]; ps1 = Bl[S1]; }
-            float vo0, vo1, g0, g1, h0, h1;
-            element_op<MODE>(v.x, ga0, ps0, a.add, vo0, g0, h0);
-            element_op<MODE>(v.y, ga1, ps1, a.add, vo1, g1, h1);
-            if constexpr (TR::kWrite) __builtin_nontemporal_store(f32x2{vo0, vo1}, val2 + (size_t) j * 64);
-            if constexpr (TR::kDot) {
-                // heads: slot 0 starts a run if the previous lane's slot 1 belongs to another segment
-                const uint32_t Sp = dpp_prev_lane(S1);
-                const bool hd0 = lane == 0 || S0 != Sp, hd1 = S1 != S0;
-                float xg = hd1 ? g1 : g0 + g1, xh = hd1 ? h1 : h0 + h1;  // the lane's part of the run open at its end
-                const bool seen = hd0 || hd1;
-                const uint64_t M = __ballot(seen);
-                const uint64_t upto = M & ((uint64_t(2) << lane) - 1);  // head lanes <= this lane (lane 0 always is one)
-                const uint32_t dist = lane - (63u - (uint32_t) __clzll((long long) upto));
-                seg_scan2(xg, xh, lane, dist);
-                const float eg = dpp_mov<kDppWaveShr1>(xg), eh = dpp_mov<kDppWaveShr1>(xh);  // run open at the end of lane l-1
-                if (hd0 && lane > 0) {  // that run ended with the previous lane
-                    float2 t2 = ghl[Sp];
-                    t2.x += eg; t2.y += eh;
-                    ghl[Sp] = t2;
-                }
-                if (hd1) {  // the run that ends with this lane's slot 0
-                    float2 t2 = ghl[S0];
-                    t2.x += hd0 ? g0 : eg + g0; t2.y += hd0 ? h0 : eh + h0;
-                    ghl[S0] = t2;
-                }
-                if (lane == 63) {  // runs never cross a sub-tile: the open one ends here
-                    float2 t2 = ghl[S1];
-                    t2.x += xg; t2.y += xh;
-                    ghl[S1] = t2;
-                }
-            }
-            j += 16;
-        }
-        if (j_n == kNoSub && nx_ok) issue(nx_first);
-        if (more) store_stage(nxt);
-        __syncthreads();
-    }
-    if constexpr (TR::kDot)
-        for (uint32_t i = tid; i < nsl; i += kTileBlock) a.gh_part[(size_t) r * a.part_stride + seg0 + i] = ghl[i];
-}
-
-// dense gh[0..nseg) = g, gh[nseg..2 nseg) = h from the R strips, added in strip order
-__global__ __launch_bounds__(kBlock) void k_tile_combine(uint32_t nseg, uint32_t R, uint32_t stride,
-                                                         const float2* __restrict__ part, float* __restrict__ gh) {
-    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= nseg) return;
-    float g = 0.f, h = 0.f;
-    for (uint32_t r = 0; r < R; ++r) {
-        const float2 x = part[(size_t) r * stride + c];
-        g += x.x; h += x.y;
-    }
-    gh[c] = g;
-    gh[nseg + c] = h;
-}
-
 // Adds, in span order, the carries that belong to the stored range [lo, hi).
 __device__ __forceinline__ void add_carries(uint32_t lo, uint32_t hi, uint32_t span_len, const float2* __restrict__ carry,
                                             float& g, float& h) {
@@ -686,8 +505,6 @@ struct FinKernelArgs {
     GatherPartsArgs parts;
     const uint32_t* seg_cnt;
     const float* gh_dense;
-    const float2* tile_part;  // tile layout: [tile_R][tile_stride] strip partials
-    uint32_t tile_R, tile_stride;
     const uint32_t* cnt_override;
     float lambda;
     float* out_vec;
@@ -702,7 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     // old pack entry, next vector entry) before the partial sums are chased, so that those loads do
     // not queue up behind the rank -> part -> (barrier) chain.
     constexpr int SEGS = kBlock / PL;
-    const bool flat = !a.gh_dense && !a.tile_part;
+    const bool flat = !a.gh_dense;
     const uint32_t c0 = flat ? blockIdx.x * SEGS + threadIdx.x % SEGS : blockIdx.x * kBlock + threadIdx.x;
     const bool owner = c0 < a.parts.nseg && (!flat || threadIdx.x / SEGS == 0);
     uint32_t cnt = 0;
@@ -719,14 +536,6 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
         if (c >= a.parts.nseg) return;
         g = a.gh_dense[c];
         h = a.gh_dense[a.parts.nseg + c];
-    } else if (a.tile_part) {  // PL == 1: strips added in order
-        c = c0;
-        if (c >= a.parts.nseg) return;
-        g = 0.f; h = 0.f;
-        for (uint32_t r = 0; r < a.tile_R; ++r) {
-            const float2 x = a.tile_part[(size_t) r * a.tile_stride + c];
-            g += x.x; h += x.y;
-        }
     } else if (!block_segment_sums<PL>(a.parts, c, g, h)) {
         return;
     }
@@ -816,6 +625,14 @@ __global__ void k_sum_partials(uint32_t n, const double* __restrict__ partials, 
     if (threadIdx.x == 0) *out = acc;
 }
 
+__global__ __launch_bounds__(kBlock) void k_check_range(uint64_t n, const uint32_t* __restrict__ idx, uint32_t bound,
+                                                         unsigned long long* __restrict__ first_bad) {
+    unsigned long long bad = ~0ull;
+    for (uint64_t q = (uint64_t) blockIdx.x * kBlock + threadIdx.x; q < n; q += (uint64_t) gridDim.x * kBlock)
+        if (idx[q] >= bound && q < bad) bad = q;
+    if (bad != ~0ull) atomicMin(first_bad, bad);
+}
+
 uint32_t seg_grid(uint32_t nseg) {
     // wave-per-segment kernels grid-stride; 8 blocks per CU is plenty
     const uint32_t want = (nseg + (kBlock / 64) - 1) / (kBlock / 64);
@@ -826,17 +643,32 @@ uint32_t seg_grid(uint32_t nseg) {
 
 #define MFX_LAUNCH_CHECK() MFX_HIP(hipGetLastError())
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, and one process may
+// drive several devices from several threads (mfx_train -nGPUs): remember what was set per
+// (instantiation, device), under a lock.
+namespace {
+struct LdsAttrCache {
+    std::mutex m;
+    size_t bytes[64] = {};
+};
+int ensure_dynamic_lds(const void* kernel, LdsAttrCache& c, size_t lds_bytes) {
+    int dev = 0;
+    MFX_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(c.m);
+    if (dev >= 0 && dev < 64 && lds_bytes <= c.bytes[dev]) return MFX_OK;
+    MFX_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+    if (dev >= 0 && dev < 64) c.bytes[dev] = lds_bytes;
+    return MFX_OK;
+}
+}  // namespace
+
 template <int MODE, bool LDS, int BLOCK, bool PSCHK>
 int launch_flat_t(const FlatArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
     if (lds_bytes > 48 * 1024) {
-        static size_t attr_bytes = 0;  // per instantiation
-        if (lds_bytes > attr_bytes) {
-            MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat<MODE, LDS, BLOCK, PSCHK>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-            attr_bytes = lds_bytes;
-        }
+        static LdsAttrCache cache;  // per instantiation
+        MFX_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_flat<MODE, LDS, BLOCK, PSCHK>), cache, lds_bytes));
     }
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL((k_flat<MODE, LDS, BLOCK, PSCHK>), dim3(grid), dim3(BLOCK), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_flat<MODE, LDS, BLOCK, PSCHK>), dim3(grid), dim3(BLOCK), lds_bytes, st, a);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }
@@ -864,39 +696,8 @@ int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
     }
 }
 
-template <int MODE>
-int launch_tile_mode(const SegStreamDev& s, const TileArgs& a, hipStream_t st) {
-    const size_t lds_bytes = TileLds<MODE>::total(s.t_QB, s.t_SR);
-    MFX_REQUIRE(lds_bytes <= 160 * 1024 && s.t_SR <= (uint32_t) kTileStage * kTileBlock, "tile layout does not fit the kernel");
-    static size_t attr_bytes = 0;  // per instantiation
-    if (lds_bytes > attr_bytes) {
-        MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int) lds_bytes));
-        attr_bytes = lds_bytes;
-    }
-    MFX_CLEAR_STALE_ERROR();
-    hipLaunchKernelGGL(k_tile<MODE>, dim3(s.t_nB * s.t_R), dim3(kTileBlock), lds_bytes, st, a);
-    MFX_LAUNCH_CHECK();
-    return MFX_OK;
-}
-
-static int launch_tile(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, int add, hipStream_t st) {
-    TileArgs a;
-    a.code = s.t_code; a.val = s.val; a.tile_sub = s.t_tile_sub; a.nseg = s.nseg; a.gather_len = s.gather_len;
-    a.QB = s.t_QB; a.SR = s.t_SR; a.nP = s.t_nP; a.R = s.t_R; a.part_stride = s.t_stride;
-    a.gather = gather; a.perseg = perseg; a.gh_part = s.t_gh_part; a.add = add;
-    switch (mode) {
-        case FM_SWEEP: return launch_tile_mode<FM_SWEEP>(s, a, st);
-        case FM_RESID: return launch_tile_mode<FM_RESID>(s, a, st);
-        case FM_FCSC: return launch_tile_mode<FM_FCSC>(s, a, st);
-        case FM_FCSR: return launch_tile_mode<FM_FCSR>(s, a, st);
-        default: return fail(MFX_ERR_INVALID, "launch_tile: bad mode %d", (int) mode);
-    }
-}
-
 int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, int add,
                 hipStream_t st) {
-    if (s.tile) return launch_tile(mode, s, gather, perseg, add, st);
     FlatArgs a;
     a.idx = s.lds_panels ? static_cast<const void*>(s.idx16) : static_cast<const void*>(s.idx);
     a.val = s.val; a.flags32 = s.flags32; a.hpre = s.hpre; a.seg_of_rank = s.seg_of_rank;
@@ -914,10 +715,27 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
     }
 }
 
+int check_index_range(const uint32_t* d_idx, uint64_t n, uint32_t bound, const char* what, hipStream_t st) {
+    if (n == 0) return MFX_OK;
+    DevBuf<unsigned long long> flag;
+    MFX_TRY(flag.alloc(1));
+    MFX_HIP(hipMemsetAsync(flag.get(), 0xFF, sizeof(unsigned long long), st));
+    const uint32_t grid = (uint32_t) std::min<uint64_t>((n + kBlock - 1) / kBlock, 256 * 8);
+    hipLaunchKernelGGL(k_check_range, dim3(grid), dim3(kBlock), 0, st, n, d_idx, bound, flag.get());
+    MFX_LAUNCH_CHECK();
+    unsigned long long bad = ~0ull;
+    MFX_HIP(hipMemcpyAsync(&bad, flag.get(), sizeof(bad), hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    if (bad == ~0ull) return MFX_OK;
+    uint32_t v = 0;
+    MFX_HIP(hipMemcpy(&v, d_idx + bad, sizeof(v), hipMemcpyDeviceToHost));
+    return fail(MFX_ERR_INVALID, "%s %u at position %llu is out of range [0, %u)", what, v, bad, bound);
+}
+
 int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, float* h_dense, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
-    MFX_REQUIRE(s.panel_rows == 0 && !s.tile, "wave-per-segment kernels need the plain layout");
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_sweep_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
+    MFX_REQUIRE(s.panel_rows == 0, "wave-per-segment kernels need the plain layout");
+    hipLaunchKernelGGL(k_sweep_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
                        vec, g_dense, h_dense);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
@@ -925,8 +743,8 @@ int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, f
 
 int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float* per_seg, int add, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
-    MFX_REQUIRE(s.panel_rows == 0 && !s.tile, "wave-per-segment kernels need the plain layout");
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_resid_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
+    MFX_REQUIRE(s.panel_rows == 0, "wave-per-segment kernels need the plain layout");
+    hipLaunchKernelGGL(k_resid_wave, dim3(seg_grid(s.nseg)), dim3(kBlock), 0, st, s.nseg, s.ptr, s.idx, s.val,
                        gathered, per_seg, add);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
@@ -943,17 +761,9 @@ static int panel_lanes(const SegStreamDev& s) { return s.npanels >= 8 ? 16 : s.n
 
 int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;
-    if (s.tile) {
-        MFX_CLEAR_STALE_ERROR();
-        hipLaunchKernelGGL(k_tile_combine, dim3((s.nseg + kBlock - 1) / kBlock), dim3(kBlock), 0, st, s.nseg, s.t_R, s.t_stride,
-                           s.t_gh_part, gh);
-        MFX_LAUNCH_CHECK();
-        return MFX_OK;
-    }
     const GatherPartsArgs a = parts_of(s);
     const int pl = panel_lanes(s);
     const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
-    MFX_CLEAR_STALE_ERROR();
     if (pl == 16) hipLaunchKernelGGL(k_combine_dense<16>, grid, block, 0, st, a, gh);
     else if (pl == 4) hipLaunchKernelGGL(k_combine_dense<4>, grid, block, 0, st, a, gh);
     else hipLaunchKernelGGL(k_combine_dense<1>, grid, block, 0, st, a, gh);
@@ -965,11 +775,9 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
     if (s.nseg == 0) return MFX_OK;
     FinKernelArgs a;
     a.parts = parts_of(s); a.seg_cnt = s.seg_cnt; a.gh_dense = f.gh_dense; a.cnt_override = f.cnt_override;
-    a.tile_part = (s.tile && !f.gh_dense) ? s.t_gh_part : nullptr; a.tile_R = s.t_R; a.tile_stride = s.t_stride;
     a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
-    const int pl = (f.gh_dense || s.tile) ? 1 : panel_lanes(s);
+    const int pl = f.gh_dense ? 1 : panel_lanes(s);
     const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
-    MFX_CLEAR_STALE_ERROR();
     if (pl == 16) hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, st, a);
     else if (pl == 4) hipLaunchKernelGGL(k_finalize<4>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_finalize<1>, grid, block, 0, st, a);
@@ -979,7 +787,7 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
 
 int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st) {
     if (s.padded_nnz == 0) return MFX_OK;
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_unpermute, dim3((uint32_t) ((s.padded_nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+    hipLaunchKernelGGL(k_unpermute, dim3((uint32_t) ((s.padded_nnz + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                        s.padded_nnz, s.perm, s.val, out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
@@ -989,7 +797,7 @@ int launch_unpermute_runs(const SegStreamDev& s, const uint32_t* first_q, const 
     const uint32_t nv = s.npanels * s.nseg;
     if (nv == 0) return MFX_OK;
     const uint32_t blocks = std::min<uint32_t>((nv + kBlock / 64 - 1) / (kBlock / 64), 65536u);
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_unpermute_runs, dim3(blocks), dim3(kBlock), 0, st, nv, s.nseg, s.ptr_v, first_q, panel_end,
+    hipLaunchKernelGGL(k_unpermute_runs, dim3(blocks), dim3(kBlock), 0, st, nv, s.nseg, s.ptr_v, first_q, panel_end,
                        s.val, out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
@@ -997,7 +805,7 @@ int launch_unpermute_runs(const SegStreamDev& s, const uint32_t* first_q, const 
 
 int launch_pack2(uint32_t n, const float* x, const float* y, float2* pack, hipStream_t st) {
     if (n == 0) return MFX_OK;
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_pack2, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, x, y, pack);
+    hipLaunchKernelGGL(k_pack2, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, n, x, y, pack);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }
@@ -1005,10 +813,10 @@ int launch_pack2(uint32_t n, const float* x, const float* y, float2* pack, hipSt
 int launch_test_sqerr(int64_t nnz_test, const uint32_t* row, const uint32_t* col, const float* val,
                       const float* W, const float* H, int64_t rows, int64_t cols, int64_t k, int ifALS,
                       double* block_partials, uint32_t nblocks, double* sum_out, hipStream_t st) {
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_test_sqerr, dim3(nblocks), dim3(kBlock), 0, st, nnz_test, row, col, val, W, H, rows,
+    hipLaunchKernelGGL(k_test_sqerr, dim3(nblocks), dim3(kBlock), 0, st, nnz_test, row, col, val, W, H, rows,
                        cols, k, ifALS, block_partials);
     MFX_LAUNCH_CHECK();
-    MFX_CLEAR_STALE_ERROR(); hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, nblocks, block_partials, sum_out);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, nblocks, block_partials, sum_out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }

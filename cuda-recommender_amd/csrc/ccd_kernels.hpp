@@ -39,13 +39,6 @@ struct SegStreamDev {
     const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id
     const uint32_t* wg_panel = nullptr;        // [nspans/spans_per_wg]
     const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding; nullptr: SegStreamStore::unpermute knows
-    // 2-D tile layout (tile_layout.hpp): replaces ptr_v / idx / flags / ranks above; val, perm, seg_cnt,
-    // nseg, nnz, padded_nnz, gather_len keep their meaning
-    bool tile = false;
-    uint32_t t_QB = 0, t_SR = 0, t_nB = 0, t_nP = 0, t_R = 1, t_stride = 0;
-    const uint32_t* t_code = nullptr;          // [padded nnz] (segment_local << 16) | index_local
-    const uint32_t* t_tile_sub = nullptr;      // [t_nB * t_nP + 1]
-    float2* t_gh_part = nullptr;               // [t_R][t_stride] strip partials written by the tile kernel
     // reduction scratch written by the flat kernels
     float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
     float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run
@@ -104,5 +97,11 @@ int launch_test_sqerr(int64_t nnz_test, const uint32_t* row, const uint32_t* col
                       int ifALS, double* block_partials, uint32_t nblocks, double* sum_out,
                       hipStream_t st);
 constexpr uint32_t kRmseBlocks = 1024;
+
+// Every idx[q] (device array, q < n) must be < bound: MFX_ERR_INVALID naming the first offender
+// otherwise ("%s index ... out of range").  Synchronises `st`.  Used on every index array that a
+// kernel will use as an address without further checks (ALS gather indices, test-set rows/columns),
+// so that a malformed input is an error message and not a GPU fault.
+int check_index_range(const uint32_t* d_idx, uint64_t n, uint32_t bound, const char* what, hipStream_t st);
 
 }  // namespace mfx

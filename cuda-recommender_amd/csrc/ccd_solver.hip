@@ -9,7 +9,6 @@
 //     order of the two updates); only the order of the fp32 reduction differs from the CPU.
 //   * mfx_params.schedule = 0 runs the kernel sequence exactly as written, for A/B and parity.
 #include "ccd_solver.hpp"
-#include "tile_layout.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -74,10 +73,6 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
         const uint64_t bad = cx.bad.load();
         MFX_REQUIRE(bad == ~0ull, "index %u at position %llu is out of range [0, %u)", idx_h[bad == ~0ull ? 0 : bad],
                     (unsigned long long) bad, G);
-    }
-    if (opt.tile_qb) {  // hyper-sparse orientation: 2-D tile order, unless the pattern does not suit it
-        TileLayoutHost T;
-        if (build_tile_layout(ptr_h, idx_h, nseg, nnz, G, opt.tile_qb, opt.tile_sr, opt.tile_max_pad, &T)) return build_tiles(T, val_h, st);
     }
     if (opt.panel_rows && opt.lds) {
         MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16,
@@ -169,7 +164,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
 }
 
 int SegStreamStore::unpermute(float* out, hipStream_t st) {
-    if (view.perm || view.tile) return launch_unpermute(view, out, st);
+    if (view.perm) return launch_unpermute(view, out, st);
     if (first_q_dev_.size() == 0 && !first_q_host_.empty()) {
         MFX_TRY(first_q_dev_.alloc(first_q_host_.size()));
         MFX_TRY(first_q_dev_.upload(first_q_host_.data(), first_q_host_.size(), MFX_HOST, st));
@@ -178,47 +173,6 @@ int SegStreamStore::unpermute(float* out, hipStream_t st) {
         MFX_HIP(hipStreamSynchronize(st));
     }
     return launch_unpermute_runs(view, first_q_dev_.get(), panel_end_dev_.get(), out, st);
-}
-
-int SegStreamStore::build_tiles(const TileLayoutHost& T, const float* val_h, hipStream_t st) {
-    std::vector<float> val_st(T.padded, 0.f);
-    if (val_h) {
-        struct Ctx { float* dst; const float* src; const uint32_t* perm; } cx{val_st.data(), val_h, T.perm.data()};
-        parallel_ranges_u64(T.padded, [](uint64_t b, uint64_t e, void* p) {
-            Ctx& c = *static_cast<Ctx*>(p);
-            for (uint64_t i = b; i < e; ++i)
-                if (c.perm[i] != ~0u) c.dst[i] = c.src[c.perm[i]];
-        }, &cx);
-    }
-    // strips: as many as fill the chip best (blocks x strips workgroups, one 1024-thread workgroup per CU)
-    int ncu = 256;
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ncu = prop.multiProcessorCount;
-    }
-    uint32_t best_r = 1;
-    double best_fill = 0.0;
-    for (uint32_t r = 1; r <= 8 && r <= T.nP; ++r) {
-        const uint64_t wgs = (uint64_t) T.nB * r;
-        const double fill = (double) wgs / (double) (((wgs + ncu - 1) / ncu) * ncu);
-        if (fill > best_fill + 0.02) { best_fill = fill; best_r = r; }
-    }
-    const uint32_t stride = T.nB * T.QB;
-    MFX_TRY(seg_cnt_.alloc(T.nseg)); MFX_TRY(seg_cnt_.upload(T.seg_cnt.data(), T.nseg, MFX_HOST, st));
-    MFX_TRY(t_code_.alloc(T.padded)); MFX_TRY(t_code_.upload(T.code.data(), T.padded, MFX_HOST, st));
-    MFX_TRY(perm_.alloc(T.padded)); MFX_TRY(perm_.upload(T.perm.data(), T.padded, MFX_HOST, st));
-    MFX_TRY(val_.alloc(T.padded)); MFX_TRY(val_.upload(val_st.data(), T.padded, MFX_HOST, st));
-    MFX_TRY(t_tile_sub_.alloc(T.tile_sub.size())); MFX_TRY(t_tile_sub_.upload(T.tile_sub.data(), T.tile_sub.size(), MFX_HOST, st));
-    MFX_TRY(t_gh_part_.alloc_zero((size_t) best_r * stride, st));
-    MFX_HIP(hipStreamSynchronize(st));
-    view = SegStreamDev();
-    view.nseg = T.nseg; view.nnz = T.nnz; view.padded_nnz = T.padded; view.gather_len = T.gather_len;
-    view.seg_cnt = seg_cnt_.get(); view.val = val_.get(); view.perm = perm_.get();
-    view.tile = true; view.t_QB = T.QB; view.t_SR = T.SR; view.t_nB = T.nB; view.t_nP = T.nP; view.t_R = best_r;
-    view.t_stride = stride; view.t_code = t_code_.get(); view.t_tile_sub = t_tile_sub_.get(); view.t_gh_part = t_gh_part_.get();
-    return MFX_OK;
 }
 
 // LDS panels pay off when the gathered vector is too big for L1 yet cutting it into LDS-sized
@@ -231,11 +185,6 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     o.spans_per_wg = p.wg_waves > 0 ? (uint32_t) p.wg_waves : 16;
     o.panel_rows = 0;
     if (need_plain || p.panel_rows == -1) return o;
-    if (p.tile > 0) {  // forced 2-D tiles (test hook); what follows describes the fallback
-        o.tile_qb = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t) p.tile & 0xFFFFu, nseg ? nseg : 1u));
-        o.tile_sr = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t) p.tile >> 16, 5120u), G ? G : 1u));
-        o.tile_max_pad = 1.0;
-    }
     if (p.panel_rows < -1) {  // explicit cache panels of -panel_rows entries
         o.panel_rows = std::min<uint32_t>((uint32_t) -p.panel_rows, G ? G : 1u);
         o.lds = false;
@@ -258,8 +207,6 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
         // pair).  Cut at L2 granularity instead: 2 MB slices keep every gather an L2 hit (measured,
         // tools/ubench_gather.hip sweep: 100 M 8-byte gathers take 0.60 ms against a 2 MB table, 1.01 ms
         // against 8 MB), with whole segments of >= 8 entries per slice or not at all.
-        // (The 2-D tile order of tile_layout.hpp -- both operands in LDS -- is NOT chosen here: at this
-        // density a slice serves too few entries; mfx_params.tile > 0 forces it.)
         const uint32_t cpr = (2u << 20) / elem_bytes;
         if (cpr >= G) return o;
         const uint64_t cpanels = (G + cpr - 1) / cpr;
@@ -381,8 +328,10 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // overlap the parallel passes of the other).  Error text is thread-local, so carry it across.
     int rc_csr = MFX_OK;
     std::string err_csr;
-    // (host allocations of several GB can fail: no exception may leave a thread or cross the C ABI)
-    std::thread csr_thread([&] {
+    // (host allocations of several GB can fail: no exception may leave a thread or cross the C ABI;
+    // ThreadGang runs the job inline when no thread can be started and joins in its destructor)
+    ThreadGang csr_gang;
+    csr_gang.run([&] {
         try {
             rc_csr = use_device(device_);
             if (rc_csr == MFX_OK)
@@ -400,7 +349,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     } catch (const std::exception& ex) {
         rc_csc = fail(MFX_ERR_ALLOC, "building the CSC copy failed: %s", ex.what());
     }
-    csr_thread.join();
+    csr_gang.wait();
     if (rc_csc != MFX_OK) return rc_csc;
     if (rc_csr != MFX_OK) { last_error() = err_csr; return rc_csr; }
 
@@ -418,10 +367,9 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         MFX_TRY(global_col_nnz_.alloc(n_));
         MFX_TRY(global_col_nnz_.upload(shard->global_col_nnz, n_, space, st_));
         global_test_nnz_ = shard->global_test_nnz;
-        // RCCL builds its rings / connections lazily, inside the first collective: take that hit here,
-        // in setup, with an all-reduce of the (still zero) column buffer, not inside the first iteration.
-        MFX_TRY(comm_allreduce_f32(comm_, gh_cols_.get(), (size_t) 2 * n_, st_));
-        MFX_HIP(hipStreamSynchronize(st_));
+        // No collective in here: a rank whose setup fails must not leave the others inside one.  The
+        // ranks meet in mfx_comm_agree() after create (which also takes RCCL's lazy connection setup),
+        // and the first iterate() call warms the data-path all-reduce up outside its timed span.
     }
     nnz_test_ = T ? T->nnz : 0;
     if (!comm_) global_test_nnz_ = nnz_test_;
@@ -430,6 +378,8 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         MFX_TRY(t_row_.alloc(nnz_test_)); MFX_TRY(t_row_.upload(T->row, nnz_test_, space, st_));
         MFX_TRY(t_col_.alloc(nnz_test_)); MFX_TRY(t_col_.upload(T->col, nnz_test_, space, st_));
         MFX_TRY(t_val_.alloc(nnz_test_)); MFX_TRY(t_val_.upload(T->val, nnz_test_, space, st_));
+        MFX_TRY(check_index_range(t_row_.get(), (uint64_t) nnz_test_, m_, "test-set row", st_));
+        MFX_TRY(check_index_range(t_col_.get(), (uint64_t) nnz_test_, n_, "test-set column", st_));
     }
     MFX_TRY(rmse_partials_.alloc_zero(kRmseBlocks, st_));
     MFX_TRY(rmse_sum_.alloc_zero(1, st_));
@@ -612,6 +562,14 @@ int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
     MFX_REQUIRE(n_outer >= 0, "n_outer must be >= 0");
     MFX_REQUIRE(factors_set_, "mfx_ccd_iterate: call mfx_ccd_set_factors first");
     MFX_TRY(use_device(device_));
+    if (comm_ && !comm_warm_ && n_outer > 0) {
+        // RCCL builds its rings / connections lazily, inside the first collective of a given size class:
+        // take that hit before the first timed iteration, with an all-reduce of the (still zero) column
+        // buffer.  Every rank reaches this point with the same n_outer, so the collective is matched.
+        MFX_TRY(comm_allreduce_f32(comm_, gh_cols_.get(), (size_t) 2 * n_, st_));
+        MFX_HIP(hipStreamSynchronize(st_));
+        comm_warm_ = true;
+    }
     for (int it = 0; it < n_outer; ++it) {
         const int64_t oiter = oiter_ + 1;
         double before[KernelProfiler::K_COUNT];

@@ -35,9 +35,6 @@ private:
     // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
     std::vector<uint32_t> first_q_host_, panel_end_host_;
     DevBuf<uint32_t> first_q_dev_, panel_end_dev_;
-    DevBuf<uint32_t> t_code_, t_tile_sub_;  // 2-D tile order
-    DevBuf<float2> t_gh_part_;
-    int build_tiles(const struct TileLayoutHost& T, const float* val_h, hipStream_t st);
 };
 
 // Panel size for an orientation whose largest LDS-staged pack element is `elem_bytes` wide:
@@ -84,7 +81,6 @@ public:
     int set_profile(bool on);
     void layout_info(int side, int32_t out[4]) const {
         const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
-        if (v.tile) { out[0] = (int32_t) v.t_nP; out[1] = (int32_t) v.t_SR; out[2] = 2; out[3] = (int32_t) v.t_QB; return; }
         out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
     }
 
@@ -126,6 +122,7 @@ private:
     double rank_acc_ = 0, update_acc_ = 0;  // running totals for the reference's log line
     int32_t pending_sub_ = -1; // fused schedule: rank whose new (u,v) is not yet subtracted
     bool factors_set_ = false;
+    bool comm_warm_ = false;   // the data-path all-reduce has run once (RCCL's lazy connection setup)
     KernelProfiler prof_;
     hipEvent_t ev_[6] = {};
     hipGraph_t graph_ = nullptr;          // one outer iteration of the fused schedule (k ranks x 4 launches)

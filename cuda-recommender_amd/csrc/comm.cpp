@@ -17,6 +17,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -45,6 +46,7 @@ RcclApi& api() {
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.handle, "ncclCommAbort"));  // optional
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
         a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(sym("ncclBroadcast"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
@@ -58,11 +60,16 @@ int check_api() {
     return MFX_OK;
 }
 
+// RCCL probes peers / devices with HIP calls that are allowed to fail and leaves their error code in the
+// runtime's sticky per-thread slot ("invalid device ordinal" while enumerating peers).  That slot is
+// what hipGetLastError() after OUR next kernel launch would report, so it is dropped HERE, right after
+// the RCCL call that succeeded -- and nowhere else: a launch failure of libmfx's own is never swallowed.
 #define MFX_NCCL(call)                                                                              \
     do {                                                                                            \
         ncclResult_t _r = (call);                                                                   \
         if (_r != ncclSuccess)                                                                      \
             return fail(MFX_ERR_COMM, "%s failed: %s", #call, api().GetErrorString ? api().GetErrorString(_r) : "?"); \
+        (void) hipGetLastError();                                                                   \
     } while (0)
 
 }  // namespace
@@ -81,6 +88,7 @@ struct LocalGroup {
     int arrived = 0;
     uint64_t generation = 0;
     int members = 0;
+    bool aborted = false;  // set by a rank that failed: every present and future waiter gives up
     std::vector<std::vector<unsigned char>> slots;
     std::vector<unsigned char> result;
 };
@@ -89,10 +97,19 @@ namespace {
 std::mutex g_groups_mutex;
 std::map<int, std::shared_ptr<LocalGroup>> g_groups;
 
+// RCCL communicators of this process, by the unique id they were created from: mfx_comm_abort on one
+// of them aborts every sibling too, which is what releases their collectives' kernels on the GPU.
+struct RcclPeer { std::string id; mfx_comm_s* comm; };
+std::mutex g_peers_mutex;
+std::vector<RcclPeer> g_peers;
+
 // Blocks until all ranks arrived; the last arriver runs `on_last` while the others still wait.
+// False when the group was aborted (mfx_comm_abort by a rank that failed): the collective did not
+// happen and the caller must unwind.
 template <typename F>
-void rendezvous(LocalGroup* g, F on_last) {
+bool rendezvous(LocalGroup* g, F on_last) {
     std::unique_lock<std::mutex> lk(g->m);
+    if (g->aborted) return false;
     const uint64_t gen = g->generation;
     if (++g->arrived == g->nranks) {
         on_last();
@@ -100,27 +117,49 @@ void rendezvous(LocalGroup* g, F on_last) {
         ++g->generation;
         g->cv.notify_all();
     } else {
-        g->cv.wait(lk, [&] { return g->generation != gen; });
+        g->cv.wait(lk, [&] { return g->generation != gen || g->aborted; });
+        if (g->generation == gen) return false;  // woken by the abort, not by the last arriver
     }
+    return true;
 }
+
+void abort_group(LocalGroup* g) {
+    std::lock_guard<std::mutex> lk(g->m);
+    g->aborted = true;
+    g->cv.notify_all();
+}
+
+int aborted_error() { return fail(MFX_ERR_COMM, "loopback communicator was aborted by a failing rank"); }
+
+// A local failure inside a loopback collective must not leave the other ranks waiting for this one.
+#define MFX_HIP_OR_ABORT(g, call)                                                            \
+    do {                                                                                     \
+        hipError_t _e = (call);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            abort_group(g);                                                                  \
+            return ::mfx::fail(MFX_ERR_HIP, "%s failed: %s (%s:%d)", #call,                  \
+                               hipGetErrorString(_e), __FILE__, __LINE__);                   \
+        }                                                                                    \
+    } while (0)
 
 template <typename T>
 int local_allreduce(mfx_comm_s* c, T* buf, size_t count, hipStream_t st) {
     LocalGroup* g = c->local;
     const size_t bytes = count * sizeof(T);
-    MFX_HIP(hipStreamSynchronize(st));
+    MFX_HIP_OR_ABORT(g, hipStreamSynchronize(st));
     g->slots[c->rank].resize(bytes);
-    MFX_HIP(hipMemcpy(g->slots[c->rank].data(), buf, bytes, hipMemcpyDeviceToHost));
-    rendezvous(g, [&] {
-        g->result.assign(bytes, 0);
-        T* acc = reinterpret_cast<T*>(g->result.data());
-        for (int r = 0; r < g->nranks; ++r) {  // rank order: reproducible
-            const T* src = reinterpret_cast<const T*>(g->slots[r].data());
-            for (size_t i = 0; i < count; ++i) acc[i] += src[i];
-        }
-    });
-    MFX_HIP(hipMemcpy(buf, g->result.data(), bytes, hipMemcpyHostToDevice));
-    rendezvous(g, [] {});  // nobody overwrites a slot before everyone has read the result
+    MFX_HIP_OR_ABORT(g, hipMemcpy(g->slots[c->rank].data(), buf, bytes, hipMemcpyDeviceToHost));
+    if (!rendezvous(g, [&] {
+            g->result.assign(bytes, 0);
+            T* acc = reinterpret_cast<T*>(g->result.data());
+            for (int r = 0; r < g->nranks; ++r) {  // rank order: reproducible
+                const T* src = reinterpret_cast<const T*>(g->slots[r].data());
+                for (size_t i = 0; i < count; ++i) acc[i] += src[i];
+            }
+        }))
+        return aborted_error();
+    MFX_HIP_OR_ABORT(g, hipMemcpy(buf, g->result.data(), bytes, hipMemcpyHostToDevice));
+    if (!rendezvous(g, [] {})) return aborted_error();  // nobody overwrites a slot before everyone has read the result
     return MFX_OK;
 }
 }  // namespace
@@ -173,7 +212,75 @@ int comm_create(mfx_comm_s** out, const void* id_bytes, int rank, int nranks, in
     h->rank = rank;
     h->nranks = nranks;
     h->device = device;
+    {
+        std::lock_guard<std::mutex> lk(g_peers_mutex);
+        g_peers.push_back({std::string(static_cast<const char*>(id_bytes), sizeof(id)), h});
+    }
     *out = h;
+    return MFX_OK;
+}
+
+// Worst status over all ranks (statuses are <= 0, so the minimum).  Every rank calls this once after
+// its own setup, successful or not, BEFORE the first data-path collective: a rank whose shard
+// extraction / solver creation failed tells the others instead of leaving them inside an all-reduce
+// that it will never join.  On RCCL it doubles as the warm-up collective (RCCL sets up its
+// connections lazily, inside the first one).
+int comm_agree(mfx_comm_s* c, int local_status, int* global_status) {
+    MFX_REQUIRE(c && global_status, "comm_agree: null argument");
+    *global_status = local_status;
+    if (c->local) {
+        LocalGroup* g = c->local;
+        {
+            std::lock_guard<std::mutex> lk(g->m);
+            if (g->slots[c->rank].size() < sizeof(int)) g->slots[c->rank].resize(sizeof(int));
+            memcpy(g->slots[c->rank].data(), &local_status, sizeof(int));
+        }
+        int worst = 0;
+        if (!rendezvous(g, [&] {
+                g->result.assign(sizeof(int), 0);
+                int w = 0;
+                for (int r = 0; r < g->nranks; ++r) {
+                    int s = 0;
+                    memcpy(&s, g->slots[r].data(), sizeof(int));
+                    if (s < w) w = s;
+                }
+                memcpy(g->result.data(), &w, sizeof(int));
+            }))
+            return aborted_error();
+        memcpy(&worst, g->result.data(), sizeof(int));
+        if (!rendezvous(g, [] {})) return aborted_error();
+        *global_status = worst;
+        return MFX_OK;
+    }
+    MFX_TRY(use_device(c->device));
+    DevBuf<int> d;
+    MFX_TRY(d.alloc(1));
+    MFX_HIP(hipMemcpy(d.get(), &local_status, sizeof(int), hipMemcpyHostToDevice));
+    MFX_NCCL(api().AllReduce(d.get(), d.get(), 1, ncclInt32, ncclMin, static_cast<ncclComm_t>(c->nccl), nullptr));
+    MFX_HIP(hipStreamSynchronize(nullptr));
+    MFX_HIP(hipMemcpy(global_status, d.get(), sizeof(int), hipMemcpyDeviceToHost));
+    return MFX_OK;
+}
+
+// Called by a rank that failed after the collectives started: releases the ranks waiting for it
+// (loopback: wakes the rendezvous; RCCL: ncclCommAbort on every communicator of the same unique id
+// in this process, which ends their collectives' kernels).  The communicator is unusable afterwards.
+int comm_abort(mfx_comm_s* c) {
+    if (!c) return MFX_OK;
+    if (c->local) { abort_group(c->local); return MFX_OK; }
+    if (!api().CommAbort) return fail(MFX_ERR_COMM, "this RCCL has no ncclCommAbort");
+    std::vector<mfx_comm_s*> group;
+    {
+        std::lock_guard<std::mutex> lk(g_peers_mutex);
+        std::string id;
+        for (const RcclPeer& p : g_peers) if (p.comm == c) id = p.id;
+        for (RcclPeer& p : g_peers) if (p.id == id && p.comm->nccl) group.push_back(p.comm);
+    }
+    for (mfx_comm_s* p : group) {
+        (void) api().CommAbort(static_cast<ncclComm_t>(p->nccl));
+        p->nccl = nullptr;  // aborted communicators are already released
+    }
+    (void) hipGetLastError();
     return MFX_OK;
 }
 
@@ -190,7 +297,15 @@ int comm_destroy(mfx_comm_s* c) {
         delete c;
         return MFX_OK;
     }
-    if (c->nccl && api().CommDestroy) (void) api().CommDestroy(static_cast<ncclComm_t>(c->nccl));
+    {
+        std::lock_guard<std::mutex> lk(g_peers_mutex);
+        for (size_t i = 0; i < g_peers.size(); ++i)
+            if (g_peers[i].comm == c) { g_peers.erase(g_peers.begin() + (long) i); break; }
+    }
+    if (c->nccl && api().CommDestroy) {
+        (void) api().CommDestroy(static_cast<ncclComm_t>(c->nccl));
+        (void) hipGetLastError();
+    }
     delete c;
     return MFX_OK;
 }
@@ -215,14 +330,14 @@ int comm_broadcast_f32(mfx_comm_s* c, float* buf, size_t count, int root, hipStr
     if (c->local) {
         LocalGroup* g = c->local;
         const size_t bytes = count * sizeof(float);
-        MFX_HIP(hipStreamSynchronize(st));
+        MFX_HIP_OR_ABORT(g, hipStreamSynchronize(st));
         if (c->rank == root) {
             g->result.resize(bytes);
-            MFX_HIP(hipMemcpy(g->result.data(), buf, bytes, hipMemcpyDeviceToHost));
+            MFX_HIP_OR_ABORT(g, hipMemcpy(g->result.data(), buf, bytes, hipMemcpyDeviceToHost));
         }
-        rendezvous(g, [] {});  // the root's data is in place
-        if (c->rank != root) MFX_HIP(hipMemcpy(buf, g->result.data(), bytes, hipMemcpyHostToDevice));
-        rendezvous(g, [] {});  // everyone has read it
+        if (!rendezvous(g, [] {})) return aborted_error();  // the root's data is in place
+        if (c->rank != root) MFX_HIP_OR_ABORT(g, hipMemcpy(buf, g->result.data(), bytes, hipMemcpyHostToDevice));
+        if (!rendezvous(g, [] {})) return aborted_error();  // everyone has read it
         return MFX_OK;
     }
     MFX_NCCL(api().Broadcast(buf, buf, count, ncclFloat32, root, static_cast<ncclComm_t>(c->nccl), st));

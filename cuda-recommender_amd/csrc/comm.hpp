@@ -20,6 +20,10 @@ int comm_unique_id(void* id_out);
 int comm_create(mfx_comm_s** out, const void* id, int rank, int nranks, int device);
 int comm_create_local(mfx_comm_s** out, int group, int rank, int nranks, int device);
 int comm_destroy(mfx_comm_s* c);
+// Collective: worst (minimum) status over all ranks; see comm.cpp.
+int comm_agree(mfx_comm_s* c, int local_status, int* global_status);
+// Releases the ranks waiting for this one after a local failure; the communicator is dead afterwards.
+int comm_abort(mfx_comm_s* c);
 // In-place sum all-reduce on `st`.
 int comm_allreduce_f32(mfx_comm_s* c, float* buf, size_t count, hipStream_t st);
 int comm_allreduce_f64(mfx_comm_s* c, double* buf, size_t count, hipStream_t st);

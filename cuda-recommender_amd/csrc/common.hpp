@@ -29,10 +29,6 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
                                hipGetErrorString(_e), __FILE__, __LINE__);                   \
     } while (0)
 
-// hipGetLastError() is process-sticky: another library's failed probe (RCCL leaves "invalid device
-// ordinal" behind while enumerating peers) would be blamed on our next launch.  Drop it first.
-#define MFX_CLEAR_STALE_ERROR() (void) hipGetLastError()
-
 #define MFX_TRY(call)                \
     do {                             \
         int _s = (call);             \

@@ -21,25 +21,11 @@ uint32_t pick_tiles_per_span(uint64_t nnz, bool panels) {
 
 // Runs fn(begin, end) over [0, n) on a few host threads (plain std::thread: libmfx must not drag
 // a second OpenMP runtime into a process that already hosts torch's).
-template <typename F>
-void parallel_ranges(uint32_t n, F fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
-    if (n < 4096 || nt == 1) { fn(0u, n); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; ++t) {
-        const uint32_t b = (uint32_t) ((uint64_t) n * t / nt), e = (uint32_t) ((uint64_t) n * (t + 1) / nt);
-        th.emplace_back([=] { fn(b, e); });
-    }
-    for (auto& x : th) x.join();
-}
-
-// Like parallel_ranges over segments, but the cuts balance the non-zeros (ptr is the prefix sum), so a
+// Like a range split over segments, but the cuts balance the non-zeros (ptr is the prefix sum), so a
 // few heavy segments do not serialise the pass.
 template <typename F>
 void parallel_segments(const uint32_t* ptr, uint32_t nseg, F fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    const unsigned nt = ThreadGang::width();
     const uint64_t nnz = ptr[nseg];
     if (nseg < 64 || nnz < (1u << 16) || nt == 1) { fn(0u, nseg); return; }
     std::vector<uint32_t> cut(nt + 1, nseg);
@@ -48,24 +34,23 @@ void parallel_segments(const uint32_t* ptr, uint32_t nseg, F fn) {
         cut[t] = (uint32_t) (std::lower_bound(ptr, ptr + nseg + 1, (uint32_t) (nnz * t / nt)) - ptr);
     for (unsigned t = 1; t <= nt; ++t) cut[t] = std::max(cut[t], cut[t - 1]);
     cut[nt] = nseg;
-    std::vector<std::thread> th;
+    ThreadGang gang;
     for (unsigned t = 0; t < nt; ++t)
-        if (cut[t + 1] > cut[t]) th.emplace_back([=] { fn(cut[t], cut[t + 1]); });
-    for (auto& x : th) x.join();
+        if (cut[t + 1] > cut[t]) gang.run([=] { fn(cut[t], cut[t + 1]); });
+    gang.wait();
 }
 
 }  // namespace
 
 void parallel_ranges_u64(uint64_t n, void (*fn)(uint64_t, uint64_t, void*), void* ctx) {
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = std::max(1u, std::min(16u, hw ? hw : 1u));
+    const unsigned nt = ThreadGang::width();
     if (n < (1u << 16) || nt == 1) { fn(0, n, ctx); return; }
-    std::vector<std::thread> th;
+    ThreadGang gang;
     for (unsigned t = 0; t < nt; ++t) {
         const uint64_t b = n * t / nt, e = n * (t + 1) / nt;
-        th.emplace_back([=] { fn(b, e, ctx); });
+        gang.run([=] { fn(b, e, ctx); });
     }
-    for (auto& x : th) x.join();
+    gang.wait();
 }
 
 void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, uint64_t nnz, uint32_t G,

@@ -37,8 +37,13 @@
 // ptr_v[v]/L < s <= (ptr_v[v+1]-1)/L -- deterministic, no atomics.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
+#include <exception>
 #include <memory>
+#include <mutex>
+#include <system_error>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -56,6 +61,47 @@ struct NoInitAllocator : std::allocator<T> {
     template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
 };
 template <typename T> using HostVec = std::vector<T, NoInitAllocator<T>>;
+
+// A few host worker threads that can neither leak nor take the process down: a thread that cannot be
+// started (std::system_error: thread limit of the container) makes the job run inline instead; the
+// destructor joins whatever was started (a joinable std::thread's destructor is std::terminate); an
+// exception thrown by a job (std::bad_alloc) is carried to wait(), which rethrows it on the caller's
+// thread, where the C ABI turns it into an error code.
+class ThreadGang {
+public:
+    ThreadGang() = default;
+    ThreadGang(const ThreadGang&) = delete;
+    ThreadGang& operator=(const ThreadGang&) = delete;
+    ~ThreadGang() { join_all(); }
+    template <typename F>
+    void run(F job) {
+        auto guarded = [this, job]() mutable {
+            try { job(); } catch (...) { std::lock_guard<std::mutex> lk(m_); if (!err_) err_ = std::current_exception(); }
+        };
+        try {
+            th_.emplace_back(guarded);
+        } catch (const std::system_error&) {
+            guarded();
+        }
+    }
+    void wait() {
+        join_all();
+        if (err_) { std::exception_ptr e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    }
+    static unsigned width() {
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::max(1u, std::min(16u, hw ? hw : 1u));
+    }
+
+private:
+    void join_all() {
+        for (std::thread& t : th_) if (t.joinable()) t.join();
+        th_.clear();
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::exception_ptr err_;
+};
 
 struct FlatLayoutHost {
     uint32_t nseg = 0;            // real segments (columns for CSC, rows for CSR)
@@ -102,10 +148,6 @@ struct FlatLayoutOptions {
     bool emit_val = false;
     bool compact_perm = false;    // see FlatLayoutHost::perm_is_runs
     const float* val = nullptr;   // input-order values for emit_val; nullptr = zeros
-    // 2-D tile order (tile_layout.hpp), tried FIRST when tile_qb != 0; the fields above then describe
-    // the fallback for patterns the tile builder refuses (a run longer than a sub-tile, too much padding)
-    uint32_t tile_qb = 0, tile_sr = 0;
-    double tile_max_pad = 0.25;   // refuse when more than this fraction of the stored slots would be padding
 };
 
 // ptr/idx are the input orientation (host pointers); G is the gathered dimension.

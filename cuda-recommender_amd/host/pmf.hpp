@@ -39,7 +39,7 @@ public:
     int schedule = 1;
     int kernel_variant = 1;
     int panel_rows = 0;
-    int tile = 0;         // mfx_params.tile
+    int layout_build = 0; // mfx_params.layout_build
     int n_gpus = 1;  // -nGPUs: user-row-block shards, one per GPU (CCD++ only)
     parameter() { snprintf(src_dir, sizeof(src_dir), "../data/simple"); }
 };

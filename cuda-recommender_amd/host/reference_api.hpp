@@ -36,7 +36,7 @@ inline mfx_params params_of(const parameter& p) {
     q.nBlocks = p.nBlocks; q.nThreadsPerBlock = p.nThreadsPerBlock;
     q.verbose = 1;  // the reference wrappers always print the per-iteration line
 #ifndef MFX_SHIM_EXTERNAL_TYPES  // knobs only this repository's `parameter` has
-    q.device = p.device; q.schedule = p.schedule; q.kernel_variant = p.kernel_variant; q.panel_rows = p.panel_rows; q.tile = p.tile;
+    q.device = p.device; q.schedule = p.schedule; q.kernel_variant = p.kernel_variant; q.panel_rows = p.panel_rows; q.layout_build = p.layout_build;
 #endif
     return q;
 }
@@ -94,8 +94,17 @@ inline void kernel_wrapper_ccdpp_multi(SparseMatrix& R, TestData& T, MatData& W,
     const int ndev = mfx_device_count();
     const bool loopback = ndev < n_shards;
     if (ndev < 1) { fprintf(stderr, "CCD FAILED: no usable HIP device\n"); return; }
+    if (n_shards < 1) { fprintf(stderr, "CCD FAILED: %d shards requested\n", n_shards); return; }
     std::vector<int64_t> bounds((size_t) n_shards + 1);
-    mfx_partition_rows(r.rows, r.csr_row_ptr, n_shards, bounds.data());
+    if (mfx_partition_rows(r.rows, r.csr_row_ptr, n_shards, bounds.data()) != MFX_OK) { fprintf(stderr, "CCD FAILED: %s\n", mfx_last_error()); return; }
+    // every shard must own at least one row (a solver rejects rows == 0, and a rank that fails while the
+    // others are inside a collective would leave them there): checked BEFORE any thread starts
+    for (int g = 0; g < n_shards; ++g)
+        if (bounds[g + 1] <= bounds[g]) {
+            fprintf(stderr, "CCD FAILED: cannot cut %lld rows into %d non-empty nnz-balanced shards (shard %d would be empty)\n",
+                    (long long) r.rows, n_shards, g);
+            return;
+        }
     std::vector<uint32_t> col_nnz((size_t) r.cols);
     for (int64_t c = 0; c < r.cols; ++c) col_nnz[c] = r.csc_col_ptr[c + 1] - r.csc_col_ptr[c];
     unsigned char uid[MFX_COMM_ID_BYTES];
@@ -129,9 +138,22 @@ inline void kernel_wrapper_ccdpp_multi(SparseMatrix& R, TestData& T, MatData& W,
         Wl[g].resize((size_t) k * nr); Hl[g].resize((size_t) k * r.cols);
         for (unsigned t = 0; t < k; ++t) for (int64_t i = 0; i < nr; ++i) Wl[g][(size_t) t * nr + i] = W[t][lo + i];
         if (rc == MFX_OK) rc = mfx_ccd_set_factors(s, Wl[g].data(), nullptr, MFX_HOST);
-        if (rc == MFX_OK) rc = mfx_ccd_iterate(s, parameters.maxiter, 1, nullptr);
-        if (rc == MFX_OK) rc = mfx_ccd_get_factors(s, Wl[g].data(), Hl[g].data(), MFX_HOST);
         if (rc != MFX_OK) errors[g] = mfx_last_error();
+        // setup is over on this rank, for better or worse: tell the others before anyone enters a collective
+        if (comm) {
+            int worst = rc;
+            const int arc = mfx_comm_agree(comm, rc, &worst);
+            if (rc == MFX_OK && arc != MFX_OK) { rc = arc; errors[g] = mfx_last_error(); }
+            if (rc == MFX_OK && worst != MFX_OK) { rc = worst; errors[g] = "another shard failed during setup"; }
+        }
+        if (rc == MFX_OK) {
+            rc = mfx_ccd_iterate(s, parameters.maxiter, 1, nullptr);
+            if (rc == MFX_OK) rc = mfx_ccd_get_factors(s, Wl[g].data(), Hl[g].data(), MFX_HOST);
+            if (rc != MFX_OK) {  // failed in mid-flight: release the ranks that wait for this one
+                errors[g] = mfx_last_error();
+                mfx_comm_abort(comm);
+            }
+        }
         mfx_ccd_destroy(s);
         mfx_comm_destroy(comm);
         status[g] = rc;

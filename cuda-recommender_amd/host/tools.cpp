@@ -179,7 +179,7 @@ parameter parse_command_line(int argc, char** argv) {
         else if (!strcmp(flag, "-device")) param.device = atoi(argv[i]);
         else if (!strcmp(flag, "-schedule")) param.schedule = atoi(argv[i]);
         else if (!strcmp(flag, "-panel")) param.panel_rows = atoi(argv[i]);
-        else if (!strcmp(flag, "-tile")) param.tile = atoi(argv[i]);
+        else if (!strcmp(flag, "-layout_build")) param.layout_build = atoi(argv[i]);
         else if (!strcmp(flag, "-nGPUs")) param.n_gpus = atoi(argv[i]);
         else if (!strcmp(flag, "-save")) { /* handled by main (it rescans argv) */ }
         else if (!strcmp(flag, "-CUDA") || !strcmp(flag, "-HIP")) { param.enable_cuda = true; --i; }  // valueless: give it back

@@ -33,7 +33,7 @@ class mfx_params(C.Structure):
                 ("nBlocks", C.c_uint32), ("nThreadsPerBlock", C.c_uint32), ("verbose", C.c_int32),
                 ("device", C.c_int32), ("schedule", C.c_int32), ("kernel_variant", C.c_int32),
                 ("profile", C.c_int32), ("tiles_per_span", C.c_int32), ("panel_rows", C.c_int32),
-                ("wg_waves", C.c_int32), ("graph", C.c_int32), ("tile", C.c_int32)]
+                ("wg_waves", C.c_int32), ("graph", C.c_int32), ("layout_build", C.c_int32)]
 
 
 class mfx_iter_report(C.Structure):
@@ -95,6 +95,8 @@ SIGNATURES = {
     "mfx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mfx_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mfx_comm_create_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mfx_comm_agree": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "mfx_comm_abort": (C.c_int, [C.c_void_p]),
     "mfx_comm_rank": (C.c_int, [C.c_void_p]),
     "mfx_comm_size": (C.c_int, [C.c_void_p]),
     "mfx_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -104,6 +106,52 @@ SIGNATURES = {
 }
 
 _LIB = None
+_HIP_RUNTIME = None  # path of the HIP runtime pinned for this process (diagnostics, tests)
+
+
+def mapped_hip_runtimes() -> list:
+    """Distinct libamdhip64 files mapped into this process (more than one = two HIP runtimes)."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
+def _pin_one_hip_runtime() -> None:
+    """One HIP runtime per process, whatever the import order.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under the SONAME of
+    /opt/rocm's (libamdhip64.so.7).  The dynamic loader reuses whichever copy is mapped first for
+    every later NEEDED entry with that SONAME, but torch's own libraries ask for the un-versioned
+    file name and so always get torch's copy: `import mfx; import torch` used to end with /opt/rocm's
+    runtime serving libmfx and torch's serving torch -- two HSA clients in one process, device
+    pointers of one unknown to the other, heap corruption at exit (seen on the GPU box, round 1).
+    So when torch is installed but not imported yet, its copy is mapped first (RTLD_GLOBAL, exactly
+    what torch's own _load_global_deps does); libmfx's NEEDED libamdhip64.so.7 then resolves to it,
+    and a later `import torch` finds the file already loaded.  MFX_HIP_RUNTIME=system opts out (for
+    processes that will never import torch)."""
+    global _HIP_RUNTIME
+    import sys
+    if os.environ.get("MFX_HIP_RUNTIME", "") == "system":
+        return
+    already = mapped_hip_runtimes()
+    if already:  # torch (or the host program) got there first: libmfx will share that copy
+        _HIP_RUNTIME = already[0]
+        return
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        _HIP_RUNTIME = cand
 
 
 def lib() -> C.CDLL:
@@ -112,7 +160,13 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise MfxError(f"{LIB_PATH} is missing: build it with `make -C {_PKG} lib` "
                            "(or __graft_entry__.build()); there is no fallback path")
+        _pin_one_hip_runtime()
         _LIB = C.CDLL(LIB_PATH)
+        two = mapped_hip_runtimes()
+        if len(two) > 1:
+            raise MfxError("two HIP runtimes are mapped into this process (" + ", ".join(two) + "): libmfx "
+                           "would not see the other runtime's device memory; import torch before mfx, or "
+                           "set MFX_HIP_RUNTIME=system in processes that never load torch")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_LIB, name)  # AttributeError here == the .so does not export the ABI
             fn.restype = res

@@ -57,7 +57,7 @@ class parameter:
         self.panel_rows = 0
         self.wg_waves = 0
         self.graph = 0
-        self.tile = 0
+        self.layout_build = 0
         self.log = 0  # print the reference's per-iteration "[-INFO-]" line
 
     def to_c(self) -> L.mfx_params:
@@ -68,7 +68,7 @@ class parameter:
         p.verbose, p.device, p.schedule = int(self.log), int(self.device), int(self.schedule)
         p.kernel_variant, p.profile, p.tiles_per_span = int(self.kernel_variant), int(self.profile), int(self.tiles_per_span)
         p.panel_rows, p.wg_waves, p.graph = int(self.panel_rows), int(self.wg_waves), int(self.graph)
-        p.tile = int(self.tile)
+        p.layout_build = int(self.layout_build)
         return p
 
 
@@ -307,6 +307,18 @@ class Comm:
         L.check(L.lib().mfx_comm_unique_id(buf))
         return buf.raw
 
+    def agree(self, local_status: int = 0) -> int:
+        """Collective: the worst status over all ranks (mfx_comm_agree).  Call it once after every rank's
+        setup, failed ranks included, before the first iterate."""
+        out = C.c_int(0)
+        L.check(L.lib().mfx_comm_agree(self.handle, int(local_status), C.byref(out)))
+        return int(out.value)
+
+    def abort(self):
+        """Releases the ranks waiting for this one after a local failure (mfx_comm_abort)."""
+        if self.handle:
+            L.lib().mfx_comm_abort(self.handle)
+
     def close(self):
         if self.handle:
             L.lib().mfx_comm_destroy(self.handle)
@@ -377,7 +389,7 @@ class CcdSolver:
             v = (C.c_int32 * 4)()
             L.check(L.lib().mfx_ccd_layout_info(self.handle, side, v))
             out[name] = {"panels": int(v[0]), "panel_rows": int(v[1]),
-                         "kind": "tile" if v[2] == 2 else "lds" if v[2] else ("cache" if v[1] else "plain"),
+                         "kind": "lds" if v[2] else ("cache" if v[1] else "plain"),
                          "tiles_per_span": int(v[3])}  # kind "tile": panel_rows = slice entries, tiles_per_span = segments per block
         return out
 

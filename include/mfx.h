@@ -91,9 +91,10 @@ typedef struct mfx_params {
     int32_t graph;             /* 0 = replay each outer iteration of the fused schedule as one hipGraph (single
                                   GPU, no per-launch profiling): removes host launch cost when the kernels are
                                   only a few microseconds long; -1 = always launch eagerly */
-    int32_t tile;              /* experimental 2-D tile order for hyper-sparse shards (both operands in LDS,
-                                  csrc/tile_layout.hpp): 0 / -1 = off (default: measured slower than cache panels
-                                  at config 5's density), > 0 = (slice entries << 16) | segments per block */
+    int32_t layout_build;      /* where the one-time panel-major layout is built: 0 = on the GPU when the pattern
+                                  allows it (inside every segment the entries of one panel are consecutive, e.g.
+                                  ascending indices -- what every CSR/CSC converter produces), else on the host;
+                                  1 = host builder; 2 = GPU builder or MFX_ERR_INVALID */
 } mfx_params;
 
 /* One outer iteration's numbers == the fields of the reference's log line
@@ -162,7 +163,7 @@ int mfx_ccd_kernel_times(mfx_ccd_t s, int cap, const char** names, double* secon
 /* Turns the per-launch event bracketing (mfx_params.profile) on or off between iterate calls. */
 int mfx_ccd_set_profile(mfx_ccd_t s, int on);
 /* Layout the solver chose for one residual copy (side 0 = CSC / column segments, 1 = CSR / row
- * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 2 tile order / 1 LDS
+ * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 1 LDS
  * panels / 0 cache panels or plain, out[3] = tiles per span (tile order: segments per block).  For logs,
  * benchmarks and tests. */
 int mfx_ccd_layout_info(mfx_ccd_t s, int side, int32_t out[4]);
@@ -235,6 +236,17 @@ int mfx_comm_create(mfx_comm_t* out, const void* id, int rank, int nranks, int d
  * host memory and summed in rank order.  Slow by design -- it exists to run the sharded solver path
  * through the real kernels where RCCL cannot (two ranks on one GPU); production uses mfx_comm_create. */
 int mfx_comm_create_local(mfx_comm_t* out, int group, int rank, int nranks, int device);
+/* Collective over all ranks: *global_status = the worst (most negative) local_status.  Protocol for a
+ * sharded solve: every rank runs its own setup (extract its shard, mfx_ccd_create / mfx_als_create_sharded,
+ * set factors), then ALL ranks -- the ones whose setup failed too, with their error code -- call this once;
+ * only if *global_status == MFX_OK does anyone go on to iterate.  No solver entry point runs a collective
+ * before its first iterate call, so a failed rank can never leave the others waiting inside one.  (On RCCL
+ * this is also where the lazy connection setup is paid.) */
+int mfx_comm_agree(mfx_comm_t c, int local_status, int* global_status);
+/* For a rank that fails AFTER the collectives started: releases the ranks waiting for it (loopback group:
+ * every present and future collective returns MFX_ERR_COMM; RCCL: ncclCommAbort on every communicator of the
+ * same unique id in this process).  The communicator can only be destroyed afterwards. */
+int mfx_comm_abort(mfx_comm_t c);
 int mfx_comm_rank(mfx_comm_t c);
 int mfx_comm_size(mfx_comm_t c);
 int mfx_comm_destroy(mfx_comm_t c);

@@ -5,15 +5,6 @@ import sys
 import numpy as np
 import pytest
 
-# One HIP runtime per process: torch bundles its own libamdhip64/librccl under the same SONAMEs as
-# /opt/rocm's.  Whichever is mapped first serves both torch and libmfx, and torch's other bundled
-# libraries expect THEIRS -- so tests that use torch (full-size generators) need torch loaded before
-# libmfx, exactly as bench.py does.  (Seen otherwise: heap corruption at interpreter exit.)
-try:
-    import torch  # noqa: F401
-except Exception:  # pragma: no cover - torch is optional for the CPU-only tests
-    torch = None
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "cuda-recommender_amd")):
     if p not in sys.path:

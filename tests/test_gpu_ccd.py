@@ -130,11 +130,11 @@ def test_test_rmse_matches_calrmse(mfx, orc, name):
 
 
 # ------------------------------------------------------------------ whole solves, golden
-def _params(mfx, k, lam, t, T, schedule, variant, tiles=0, panel_rows=0, wg_waves=0, tile=0):
+def _params(mfx, k, lam, t, T, schedule, variant, tiles=0, panel_rows=0, wg_waves=0, layout_build=0):
     p = mfx.parameter()
     p.k, p.lambda_, p.maxiter, p.maxinneriter = k, lam, t, T
     p.schedule, p.kernel_variant, p.tiles_per_span = schedule, variant, tiles
-    p.panel_rows, p.wg_waves, p.tile = panel_rows, wg_waves, tile
+    p.panel_rows, p.wg_waves, p.layout_build = panel_rows, wg_waves, layout_build
     return p
 
 
@@ -179,45 +179,44 @@ def test_residual_state_matches_reference(mfx, name, schedule, variant, panel_ro
     assert np.max(np.abs(csr - g["ccd_T1__csr_val_final"])) < 2e-4
 
 
-# forced 2-D tile order, (slice entries << 16) | segments per block: tiny tiles (many blocks, panels
-# and strips), medium, and the production size (one block / one slice on these inputs)
-TILES = [(7 << 16) | 5, (50 << 16) | 64, (4608 << 16) | 4608]
-
-
-@pytest.mark.parametrize("tile", TILES)
+# The one-time layout build has two implementations -- a device pipeline (default for grouped patterns)
+# and the host builder (fallback, and the checker): they must produce the SAME stored order, hence
+# bitwise identical factors, RMSE and residual copies, for every layout kind.
+@pytest.mark.parametrize("panel_rows", [0, 24, -24, -1])
 @pytest.mark.parametrize("tag", ["ccd_T1", "ccd_T3"])
 @pytest.mark.parametrize("name", CASES)
-def test_ccdpp_tile_order_matches_reference_golden(mfx, name, tag, tile):
+def test_device_built_layout_equals_host_built(mfx, name, tag, panel_rows):
     g, d = load_golden(name)
     k, lam = int(g["k"][0]), float(g["lam"][0])
     t, T = int(g[tag + "__maxiter"][0]), int(g[tag + "__maxinner"][0])
-    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, T, 1, 1, tile=tile))
-    info = s.layout_info()
-    s.set_factors(np.array(g[tag + "__W0"], np.float32, copy=True))
-    reports = s.iterate(t)
-    W, H = s.get_factors()
-    csc, csr = s.get_residual(d.nnz)
-    s.close()
-    # whole-matrix tiles may hold runs longer than a sub-tile (a dense column): the builder then refuses
-    # and the flat layout takes over -- legal; the small tiles must always build
-    assert d.nnz == 0 or tile == TILES[2] or (info["csc"]["kind"] == "tile" and info["csr"]["kind"] == "tile"), info
-    assert relerr(W, g[tag + "__W"]) < 2e-3 and relerr(H, g[tag + "__H"]) < 2e-3
-    assert np.all(np.abs(np.array([r.rmse for r in reports]) - g[tag + "__rmse"]) < 1e-4)
-    if tag == "ccd_T1":
-        assert np.max(np.abs(csc - g["ccd_T1__csc_val_final"])) < 2e-4
-        assert np.max(np.abs(csr - g["ccd_T1__csr_val_final"])) < 2e-4
+    out = []
+    for layout_build in (1, 2):
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, T, 1, 1, panel_rows=panel_rows, layout_build=layout_build))
+        info = s.layout_info()
+        s.set_factors(np.array(g[tag + "__W0"], np.float32, copy=True))
+        reports = s.iterate(t)
+        W, H = s.get_factors()
+        csc, csr = s.get_residual(d.nnz)
+        s.close()
+        out.append((info, [r.rmse for r in reports], W, H, csc, csr))
+    (i1, r1, W1, H1, c1, q1), (i2, r2, W2, H2, c2, q2) = out
+    assert i1 == i2 and r1 == r2
+    assert np.array_equal(bits(W1), bits(W2)) and np.array_equal(bits(H1), bits(H2))
+    assert np.array_equal(bits(c1), bits(c2)) and np.array_equal(bits(q1), bits(q2))
+    assert relerr(W2, g[tag + "__W"]) < 2e-3 and relerr(H2, g[tag + "__H"]) < 2e-3
+    assert np.all(np.abs(np.array(r2) - g[tag + "__rmse"]) < 1e-4)
 
 
 # ------------------------------------------------------------------ whole solves, ML-1M shape
-@pytest.mark.parametrize("schedule,variant,tiles,panel_rows,wg_waves,tile", [
+@pytest.mark.parametrize("schedule,variant,tiles,panel_rows,wg_waves,layout_build", [
     (1, 1, 0, 0, 0, 0), (1, 1, 2, 1000, 4, 0), (1, 1, 16, 500, 16, 0), (1, 1, 4, -1, 0, 0), (1, 1, 8, 2048, 8, 0),
     (0, 0, 0, 0, 0, 0), (0, 1, 4, 700, 8, 0), (1, 1, 4, -700, 0, 0), (1, 1, 0, -2000, 0, 0),
-    (1, 1, 0, 0, 0, (300 << 16) | 500), (0, 1, 0, 0, 0, (1000 << 16) | 256)])
-def test_ccdpp_ml1m_shape_vs_oracle(mfx, orc, medium, schedule, variant, tiles, panel_rows, wg_waves, tile):
+    (1, 1, 0, 0, 0, 1), (1, 1, 8, 2048, 8, 1), (0, 1, 0, -2000, 0, 1)])
+def test_ccdpp_ml1m_shape_vs_oracle(mfx, orc, medium, schedule, variant, tiles, panel_rows, wg_waves, layout_build):
     d, k, lam, t = medium, 40, 0.05, 3
     W0 = mfx.initial_col(k, d.rows)
     Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, 1, orc.max_threads())
-    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, 1, schedule, variant, tiles, panel_rows, wg_waves, tile))
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, 1, schedule, variant, tiles, panel_rows, wg_waves, layout_build))
     s.set_factors(W0.copy())
     reports = s.iterate(t)
     W, H = s.get_factors()

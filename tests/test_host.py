@@ -227,3 +227,26 @@ int main() { return 0; }
                         "-o", str(tmp_path / "dropin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert subprocess.run([str(tmp_path / "dropin")]).returncode == 0
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """`import mfx` before `import torch` must not leave two libamdhip64 copies in the process (torch
+    bundles its own under /opt/rocm's SONAME): mfx/_lib.py maps torch's copy first when torch is installed."""
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import mfx; from mfx import _lib; _lib.lib()\n"
+            "a = _lib.mapped_hip_runtimes()\n"
+            "import torch\n"
+            "b = _lib.mapped_hip_runtimes()\n"
+            "print(len(a), len(b), a == b)\n") % os.path.join(ROOT, "cuda-recommender_amd")
+    env = {k: v for k, v in os.environ.items() if k != "MFX_HIP_RUNTIME"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["1", "1", "True"], r.stdout
+    # the detector itself: with the pin switched off the same sequence maps two runtimes
+    env["MFX_HIP_RUNTIME"] = "system"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split()[:2] == ["1", "2"], r.stdout

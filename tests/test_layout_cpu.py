@@ -13,12 +13,3 @@ def test_layout_emulator(tmp_path):
                     os.path.join(src, "flat_layout.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
     assert "cases ok" in out, out
-
-
-def test_tile_emulator(tmp_path):
-    src = os.path.join(ROOT, "cuda-recommender_amd", "csrc")
-    exe = str(tmp_path / "tile_emulator")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", src, os.path.join(ROOT, "tests", "cpp", "tile_emulator.cpp"),
-                    os.path.join(src, "tile_layout.cpp"), "-o", exe], check=True)
-    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
-    assert "cases ok" in out, out

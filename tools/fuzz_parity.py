@@ -51,11 +51,11 @@ for case in range(a.cases):
     T = int(rng.choice([1, 1, 2, 3]))
     t = int(rng.choice([1, 2, 3]))
     p = mfx.parameter(); p.k, p.lambda_, p.maxiter, p.maxinneriter = k, lam, t, T
-    lay = rng.choice(["auto", "auto", "lds", "cache"] if a.big else ["auto", "plain", "lds", "cache", "tile", "wave", "written_flat"])
+    lay = rng.choice(["auto", "auto", "lds", "cache"] if a.big else ["auto", "plain", "lds", "cache", "hostbuilt", "wave", "written_flat"])
     if lay == "plain": p.panel_rows = -1
     elif lay == "lds": p.panel_rows = int(rng.choice([16, 100, 1000, 7000]))
     elif lay == "cache": p.panel_rows = -int(rng.choice([16, 100, 5000]))
-    elif lay == "tile": p.tile = (int(rng.choice([3, 50, 900, 4608])) << 16) | int(rng.choice([2, 64, 1000, 4608]))
+    elif lay == "hostbuilt": p.layout_build = 1
     elif lay == "wave": p.schedule, p.kernel_variant = 0, 0
     elif lay == "written_flat": p.schedule, p.kernel_variant, p.panel_rows = 0, 1, int(rng.choice([0, 50, -50]))
     p.tiles_per_span = int(rng.choice([0, 2, 4, 16]))
