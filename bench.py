@@ -2,7 +2,7 @@
 """bench.py -- CCD++ outer-iteration throughput on MI355X (BASELINE.json metric:
 "rating-nnz/sec per CCD++ outer iter at k=64").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: starts N worker processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is ONE full CCD++ outer iteration (all k ranks: subtract + add-back + v-sweep + u-sweep
@@ -11,6 +11,10 @@ for every rank, T = 1) over a synthetic Netflix-shaped rating matrix that is gen
 every rank owns one user-row block of that size (weak scaling: the global matrix has N x the
 rows and N x the non-zeros) and the ranks exchange one RCCL all-reduce of the (g, h) column
 partials per inner iteration.  Inputs are resident in HBM when the timed region starts.
+
+--workload config5 switches to BASELINE configs[4]: ONE global 10M x 1M matrix with 1e9 ratings, k = 128,
+row-sharded over the N ranks (strong scaling: every rank draws the same matrix from the same seed and
+keeps its nnz-balanced row block), 8 MB all-reduce per inner iteration.
 
 The JSON line also carries
   roofline      the dominant kernel's algorithmic bytes / its mean launch time (HIP events on the
@@ -81,6 +85,59 @@ def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
     s.close()
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_workers(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this script (one
+    per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), relay rank 0's
+    stdout (the single JSON line), exit with the workers' status.  Runs before anything touches the GPU."""
+    import subprocess
+    env0 = dict(os.environ)
+    env0.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+                 "LOCAL_WORLD_SIZE": str(n)})
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:
+            p.kill()  # the exact children started above, nothing else
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def dry_run(a) -> None:
+    """Rehearsal of the launch plumbing without a GPU: the ranks meet over gloo, all-reduce their rank
+    numbers and rank 0 prints one JSON line.  (tests/test_host.py runs it with 2 processes.)"""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t[0]), "workload": a.workload}), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +167,22 @@ def main() -> None:
     ap.add_argument("--no-rank-one", action="store_true",
                     help="skip the standalone rank-one sweep measurement (one extra outer iteration at T = 2, N = 1 only)")
     ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
+    ap.add_argument("--workload", choices=["netflix", "config5"], default="netflix",
+                    help="netflix: BASELINE configs[2], one 480189-row block per GPU (weak scaling, the metric's "
+                         "config); config5: BASELINE configs[4], one global 10M x 1M x 1e9 matrix at k = 128 "
+                         "row-sharded over the ranks (strong scaling)")
+    ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU)")
     a = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:  # bare `python bench.py --gpus N`: be the launcher
+        raise SystemExit(launch_workers(a.gpus, sys.argv[1:]))
+    if a.dry_run:
+        return dry_run(a)
+    if a.workload == "config5":  # shape defaults of configs[4] unless given explicitly
+        given = {x.split("=")[0] for x in sys.argv[1:] if x.startswith("--")}
+        if "--rows" not in given: a.rows = 10_000_000
+        if "--cols" not in given: a.cols = 1_000_000
+        if "--nnz" not in given: a.nnz = 1_000_000_000
+        if "--k" not in given: a.k = 128
 
     import numpy as np
     import torch
@@ -120,7 +192,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
@@ -133,7 +205,14 @@ def main() -> None:
 
     # ---------------- synthetic input, generated in HBM ----------------
     t0 = time.time()
-    d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed + 7919 * rank, device=dev)
+    strong = a.workload == "config5"
+    if strong:
+        # every rank draws the SAME global matrix and keeps its nnz-balanced block of user rows;
+        # uniform user activity / mild item skew: config 5 is "synthetic 10M x 1M", not a Netflix-shaped one
+        d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed, device=dev, sigma_rows=0.5, sigma_cols=1.0,
+                                             shard=(rank, world))
+    else:
+        d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed + 7919 * rank, device=dev)
     nnz_local = int(d["csr_val"].numel())
     col_cnt = (d["csc_col_ptr"][1:] - d["csc_col_ptr"][:-1]).to(torch.int32).contiguous()
     nnz_tot = torch.tensor([nnz_local, int(d["test_val"].numel())], dtype=torch.int64, device=dev)
@@ -157,9 +236,20 @@ def main() -> None:
     p.schedule, p.kernel_variant, p.tiles_per_span = a.schedule, a.variant, a.tiles
     p.panel_rows, p.wg_waves, p.graph, p.layout_build = a.panel_rows, a.wg_waves, a.graph, a.layout_build
     t0 = time.time()
-    solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt if comm else None,
-                           global_test_nnz=ntest_global, device_arrays=d)
-    setup_s = time.time() - t0  # one-time: host-side panel layout build + upload
+    solver, status = None, 0
+    try:
+        solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt if comm else None,
+                               global_test_nnz=ntest_global, device_arrays=d)
+    except mfx.MfxError as ex:
+        if comm is None:
+            raise
+        status = -1
+        print(f"[rank {rank}] solver creation failed: {ex}", file=sys.stderr, flush=True)
+    if comm is not None:  # nobody enters a collective unless everybody's setup succeeded
+        worst = comm.agree(status)
+        if worst != 0:
+            raise SystemExit(f"[rank {rank}] a rank failed during setup (status {worst})")
+    setup_s = time.time() - t0  # one-time: panel layout build (+ RCCL connection setup when sharded)
     layout = solver.layout_info()
     W0 = mfx.initial_col(a.k, int(d["rows"]))  # reference init (glibc rand, seed 0), src/tools.cpp:165-173
     solver.set_factors(W0)
@@ -285,13 +375,18 @@ def main() -> None:
         out = {
             "metric": "rating-nnz/sec per CCD++ outer iter at k=64", "value": round(value, 1), "unit": "nnz/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Netflix-shaped synthetic (BASELINE configs[2]): per-GPU "
-                                   f"{a.rows}x{a.cols}, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam}",
-                       "rows_per_gpu": a.rows, "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": (f"synthetic (BASELINE configs[4]): ONE global {a.rows}x{a.cols}, nnz={nnz_global}, "
+                                    f"k={a.k}, T={a.inner}, lambda={a.lam}, nnz-balanced user-row blocks over {world} GPU(s)")
+                                   if strong else
+                                   ("Netflix-shaped synthetic (BASELINE configs[2]): per-GPU "
+                                    f"{a.rows}x{a.cols}, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam}"),
+                       "rows_per_gpu": int(d["rows"]), "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
                        "inner_iters": a.inner, "schedule": "fused" if a.schedule == 1 else "as-written",
                        "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},
             "roofline": roofline, "rank_one_kernel": rank_one, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "allreduce_us_per_inner_iter": (kernels["rccl_allreduce"]["avg_us"] if "rccl_allreduce" in kernels else None),
             "layout": layout, "test_rmse_after": round(rmse_now, 6), "gen_seconds": round(gen_s, 2), "setup_seconds": round(setup_s, 2),
         }
         print(json.dumps(out), flush=True)

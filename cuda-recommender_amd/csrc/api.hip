@@ -276,7 +276,7 @@ int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uin
         MFX_TRY(cx.open(device));
         SegStreamStore s;
         MFX_TRY(s.build((uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, ptr, idx, val, MFX_HOST,
-                        op_layout(variant, nseg, nnz, vec_len), cx.st));
+                        op_layout(variant, nseg, nnz, vec_len), 0, cx.st));
         DevBuf<float> dvec, dout, gh;
         MFX_TRY(dvec.alloc(vec_len)); MFX_TRY(dvec.upload(vec, vec_len, MFX_HOST, cx.st));
         MFX_TRY(dout.alloc(nseg));
@@ -307,7 +307,7 @@ int mfx_update_rating(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint
         MFX_TRY(cx.open(device));
         SegStreamStore s;
         MFX_TRY(s.build((uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, ptr, idx, val, MFX_HOST,
-                        op_layout(variant, nseg, nnz, vec_len), cx.st));
+                        op_layout(variant, nseg, nnz, vec_len), 0, cx.st));
         DevBuf<float> dg, dp;
         MFX_TRY(dg.alloc(vec_len)); MFX_TRY(dg.upload(gathered, vec_len, MFX_HOST, cx.st));
         MFX_TRY(dp.alloc(nseg)); MFX_TRY(dp.upload(per_seg, nseg, MFX_HOST, cx.st));

@@ -9,6 +9,7 @@
 //     order of the two updates); only the order of the fp32 reduction differs from the CPU.
 //   * mfx_params.schedule = 0 runs the kernel sequence exactly as written, for A/B and parity.
 #include "ccd_solver.hpp"
+#include "layout_kernels.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -36,9 +37,168 @@ struct PhaseTimer {
 
 // ------------------------------------------------------------------------------------------------
 int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx,
-                          const float* val, mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st) {
-    // The layout is built on the host (one pass over the pattern, a few threads); device-resident
-    // inputs are brought down once for it.  One-time setup, outside every timed region.
+                          const float* val, mfx_memspace space, const FlatLayoutOptions& opt, int build_mode, hipStream_t st) {
+    MFX_REQUIRE(build_mode >= 0 && build_mode <= 2, "layout_build must be 0 (auto), 1 (host) or 2 (device)");
+    MFX_REQUIRE(nnz == 0 || idx, "null index array with %llu non-zeros", (unsigned long long) nnz);
+    if (opt.panel_rows && opt.lds)
+        MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16, "wg_waves must be 4, 8 or 16");
+    if (build_mode != 1) {
+        bool done = false;
+        MFX_TRY(build_device(nseg, nnz, G, ptr, idx, val, space, opt, st, &done));
+        if (done) { built_on_device_ = true; return MFX_OK; }
+        MFX_REQUIRE(build_mode != 2, "layout_build = 2: the pattern is not grouped (some segment visits a panel more than "
+                                     "once; sort the indices inside every row / column) -- the device builder cannot take it");
+    }
+    return build_host(nseg, nnz, G, ptr, idx, val, space, opt, st);
+}
+
+// Device pipeline (layout_kernels.hpp).  Host-resident inputs are uploaded as they are (12 B per
+// non-zero and orientation) and everything else happens in HBM.
+int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx,
+                                 const float* val, mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st, bool* done) {
+    *done = false;
+    PhaseTimer tm;
+    DevBuf<uint32_t> in_ptr, in_idx;
+    DevBuf<float> in_val;
+    LayoutBuildIn in;
+    in.nseg = nseg; in.nnz = nnz; in.G = G;
+    MFX_TRY(ptr_.alloc((size_t) nseg + 1));
+    MFX_TRY(ptr_.upload(ptr, (size_t) nseg + 1, space, st));
+    in.ptr = ptr_.get();
+    if (space == MFX_HOST) {
+        MFX_TRY(in_idx.alloc(nnz ? nnz : 1)); MFX_TRY(in_idx.upload(idx, nnz, MFX_HOST, st));
+        if (val) { MFX_TRY(in_val.alloc(nnz ? nnz : 1)); MFX_TRY(in_val.upload(val, nnz, MFX_HOST, st)); }
+        in.idx = in_idx.get(); in.val = val ? in_val.get() : nullptr;
+    } else {
+        in.idx = idx; in.val = val;
+    }
+    tm.lap("dev: inputs in HBM");
+    // the same derived quantities as build_flat_layout
+    const bool lds = opt.panel_rows ? opt.lds : true;
+    const uint32_t P = opt.panel_rows ? std::max(1u, (G + opt.panel_rows - 1) / opt.panel_rows) : 1u;
+    const uint32_t spans_per_wg = (opt.panel_rows && opt.lds) ? std::max(1u, opt.spans_per_wg) : 1u;
+    uint32_t tps = opt.tiles_per_span ? opt.tiles_per_span : pick_tiles_per_span(nnz, opt.panel_rows != 0 && opt.lds);
+    if (tps & 1) ++tps;
+    const uint64_t span = (uint64_t) tps * kTileElems, chunk = span * spans_per_wg;
+    const size_t nv = (size_t) P * nseg;
+    MFX_REQUIRE((uint64_t) P * nseg < 0x7FFFFFFFull, "panels x segments exceeds the 32-bit virtual-segment range");
+    if (opt.panel_rows && lds) MFX_REQUIRE(opt.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
+    in.npanels = P; in.panel_rows = opt.panel_rows; in.local_idx = opt.panel_rows != 0 && lds; in.idx16 = in.local_idx;
+    in.pad_index = opt.panel_rows ? (lds ? opt.panel_rows : G) : 0u;
+    in.span_len = (uint32_t) span; in.chunk = chunk;
+
+    MFX_TRY(lk_check_ptr(in, st));
+    DevBuf<uint32_t> cnt, S, scratch, dstart, ddelta, v_of_rank, dmax;
+    MFX_TRY(first_q_dev_.alloc(nv ? nv : 1));
+    MFX_TRY(cnt.alloc(nv ? nv : 1));
+    bool grouped = true;
+    MFX_TRY(lk_runs_and_counts(in, first_q_dev_.get(), cnt.get(), &grouped, st));
+    if (!grouped) { first_q_dev_.release(); ptr_.release(); return MFX_OK; }
+    tm.lap("dev: runs + counts");
+    // panel-major exclusive scan; panel starts -> padded panel bases (host arithmetic over P values)
+    MFX_TRY(S.alloc(nv + 1));
+    MFX_TRY(scratch.alloc(scan_scratch_words(nv)));
+    MFX_TRY(lk_exclusive_scan(cnt.get(), S.get(), nv, false, scratch.get(), st));
+    MFX_TRY(dstart.alloc((size_t) P + 1));
+    MFX_TRY(lk_panel_starts(S.get(), nseg, P, dstart.get(), st));
+    std::vector<uint32_t> ustart((size_t) P + 1), delta(P), real_end(P);
+    MFX_HIP(hipMemcpyAsync(ustart.data(), dstart.get(), sizeof(uint32_t) * ustart.size(), hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> base((size_t) P + 1);
+    uint64_t pos = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        base[p] = pos;
+        pos += ustart[p + 1] - ustart[p];
+        real_end[p] = (uint32_t) pos;
+        pos = (pos + chunk - 1) / chunk * chunk;
+    }
+    if (pos == 0) pos = chunk;  // nnz == 0: keep one (all padding) chunk so that grids are never empty
+    base[P] = pos;
+    const uint64_t padded = pos;
+    MFX_REQUIRE(padded < 0xFFFFFF00ull, "padded non-zero count exceeds the 32-bit position range");
+    for (uint32_t p = 0; p < P; ++p) delta[p] = (uint32_t) base[p] - ustart[p];
+    MFX_TRY(ddelta.alloc(P)); MFX_TRY(ddelta.upload(delta.data(), P, MFX_HOST, st));
+    MFX_TRY(ptr_v_.alloc(nv + 1));
+    MFX_TRY(lk_ptr_v(S.get(), ddelta.get(), nseg, nv, (uint32_t) padded, ptr_v_.get(), st));
+    // head bits, their prefix counts, ranks
+    const size_t nwords = padded / 32;
+    MFX_TRY(flags32_.alloc_zero(nwords + 16, st));
+    MFX_TRY(lk_heads(ptr_v_.get(), nv, flags32_.get(), st));
+    MFX_TRY(hpre_.alloc(nwords + 17));
+    if (scan_scratch_words(nwords + 16) > scratch.size()) MFX_TRY(scratch.alloc(scan_scratch_words(nwords + 16)));
+    MFX_TRY(lk_exclusive_scan(flags32_.get(), hpre_.get(), nwords + 16, true, scratch.get(), st));
+    uint32_t nne = 0;
+    MFX_HIP(hipMemcpyAsync(&nne, hpre_.get() + nwords + 16, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    MFX_REQUIRE(nne < 0x80000000u, "too many virtual segments");
+    MFX_TRY(rank_code_.alloc(nv ? nv : 1));
+    MFX_TRY(seg_of_rank_.alloc(nne ? nne : 1));
+    MFX_TRY(v_of_rank.alloc(nne ? nne : 1));
+    MFX_TRY(lk_ranks(ptr_v_.get(), nv, nseg, (uint32_t) span, flags32_.get(), hpre_.get(), rank_code_.get(), seg_of_rank_.get(),
+                     v_of_rank.get(), st));
+    tm.lap("dev: scans, heads, ranks");
+    // stored order
+    if (in.idx16) MFX_TRY(idx16_.alloc(padded)); else MFX_TRY(idx_.alloc(padded));
+    MFX_TRY(val_.alloc(padded));
+    MFX_TRY(lk_place(in, padded, ptr_v_.get(), first_q_dev_.get(), cnt.get(), flags32_.get(), hpre_.get(), v_of_rank.get(),
+                     in.idx16 ? static_cast<void*>(idx16_.get()) : static_cast<void*>(idx_.get()), val_.get(), st));
+    MFX_TRY(dmax.alloc_zero(1, st));
+    MFX_TRY(lk_max_wg_ranks(hpre_.get(), nwords, (size_t) (chunk / 32), dmax.get(), st));
+    uint32_t max_wg_ranks = 0;
+    MFX_HIP(hipMemcpyAsync(&max_wg_ranks, dmax.get(), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    // per-segment counts are the single-panel counts; with one panel that is `cnt` itself
+    MFX_TRY(seg_cnt_.alloc(nseg));
+    {
+        LayoutBuildIn one = in;
+        one.npanels = 1; one.nnz = 0;  // counts only: no index pass
+        DevBuf<uint32_t> tmp_first;
+        MFX_TRY(tmp_first.alloc(nseg));
+        bool g2 = true;
+        MFX_TRY(lk_runs_and_counts(one, tmp_first.get(), seg_cnt_.get(), &g2, st));
+    }
+    const uint32_t nspans = (uint32_t) (padded / span);
+    std::vector<uint32_t> wg_panel;
+    if (opt.panel_rows && lds) {  // workgroup -> panel (a workgroup stages exactly one slice)
+        const uint32_t nwg = nspans / spans_per_wg;
+        wg_panel.assign(nwg, 0);
+        uint32_t p = 0;
+        for (uint32_t w = 0; w < nwg; ++w) {
+            const uint64_t start = (uint64_t) w * chunk;
+            while (p + 1 < P && start >= base[p + 1]) ++p;
+            wg_panel[w] = p;
+        }
+    }
+    MFX_TRY(wg_panel_.alloc(wg_panel.empty() ? 1 : wg_panel.size()));
+    MFX_TRY(wg_panel_.upload(wg_panel.data(), wg_panel.size(), MFX_HOST, st));
+    MFX_TRY(panel_end_dev_.alloc(P)); MFX_TRY(panel_end_dev_.upload(real_end.data(), P, MFX_HOST, st));
+    MFX_TRY(part_.alloc_zero(nne ? nne : 1, st));
+    MFX_TRY(carry_.alloc_zero(nspans, st));
+    MFX_HIP(hipStreamSynchronize(st));  // host vectors behind the uploads, temporaries behind the kernels
+    tm.lap("dev: placement + rest");
+
+    layout_ = FlatLayoutHost();  // scalars only: the arrays live in HBM
+    layout_.nseg = nseg; layout_.gather_len = G; layout_.npanels = P; layout_.panel_rows = opt.panel_rows; layout_.lds = lds;
+    layout_.spans_per_wg = spans_per_wg; layout_.nne = nne; layout_.nspans = nspans; layout_.tiles_per_span = tps;
+    layout_.nnz = nnz; layout_.padded_nnz = padded; layout_.max_wg_ranks = max_wg_ranks; layout_.perm_is_runs = true;
+    view = SegStreamDev();
+    view.nseg = nseg; view.nne = nne; view.nnz = nnz; view.padded_nnz = padded; view.nspans = nspans;
+    view.tiles_per_span = tps; view.npanels = P; view.panel_rows = opt.panel_rows;
+    view.lds_panels = opt.panel_rows != 0 && lds;
+    view.spans_per_wg = spans_per_wg; view.gather_len = G;
+    view.ptr = ptr_.get(); view.ptr_v = ptr_v_.get(); view.seg_cnt = seg_cnt_.get(); view.idx = idx_.get();
+    view.idx16 = idx16_.get();
+    view.val = val_.get(); view.flags32 = flags32_.get(); view.hpre = hpre_.get(); view.rank_code = rank_code_.get();
+    view.seg_of_rank = seg_of_rank_.get(); view.max_wg_ranks = max_wg_ranks;
+    view.wg_panel = wg_panel_.get(); view.perm = nullptr; view.part = part_.get();
+    view.carry = carry_.get();
+    *done = true;
+    return MFX_OK;
+}
+
+int SegStreamStore::build_host(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx,
+                               const float* val, mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st) {
+    // The host builder (one pass over the pattern, a few threads); device-resident inputs are brought
+    // down once for it.  Takes every pattern, and is the checker of the device pipeline in the tests.
     PhaseTimer tm;
     std::vector<uint32_t> ptr_buf, idx_buf;
     std::vector<float> val_buf;
@@ -73,10 +233,6 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
         const uint64_t bad = cx.bad.load();
         MFX_REQUIRE(bad == ~0ull, "index %u at position %llu is out of range [0, %u)", idx_h[bad == ~0ull ? 0 : bad],
                     (unsigned long long) bad, G);
-    }
-    if (opt.panel_rows && opt.lds) {
-        MFX_REQUIRE(opt.spans_per_wg == 4 || opt.spans_per_wg == 8 || opt.spans_per_wg == 16,
-                    "wg_waves must be 4, 8 or 16");
     }
     tm.lap("validation");
     FlatLayoutOptions bopt = opt;  // one pass places indices (16-bit for LDS panels), provenance and values
@@ -165,7 +321,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
 
 int SegStreamStore::unpermute(float* out, hipStream_t st) {
     if (view.perm) return launch_unpermute(view, out, st);
-    if (first_q_dev_.size() == 0 && !first_q_host_.empty()) {
+    if (!built_on_device_ && first_q_dev_.size() == 0 && !first_q_host_.empty()) {
         MFX_TRY(first_q_dev_.alloc(first_q_host_.size()));
         MFX_TRY(first_q_dev_.upload(first_q_host_.data(), first_q_host_.size(), MFX_HOST, st));
         MFX_TRY(panel_end_dev_.alloc(panel_end_host_.size()));
@@ -336,7 +492,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
             rc_csr = use_device(device_);
             if (rc_csr == MFX_OK)
                 rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space,
-                                    choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), st_);
+                                    choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), p->layout_build, st_);
         } catch (const std::exception& ex) {
             rc_csr = fail(MFX_ERR_ALLOC, "building the CSR copy failed: %s", ex.what());
         }
@@ -345,7 +501,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     int rc_csc;
     try {
         rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space,
-                            choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), st_);
+                            choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), p->layout_build, st_);
     } catch (const std::exception& ex) {
         rc_csc = fail(MFX_ERR_ALLOC, "building the CSC copy failed: %s", ex.what());
     }

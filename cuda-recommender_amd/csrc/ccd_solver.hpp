@@ -18,14 +18,23 @@ class SegStreamStore {
 public:
     // ptr/idx/val live in `space` (input order).  val may be nullptr (zeros).  G = length of the
     // gathered index space.  opt.panel_rows != 0 stores the non-zeros panel-major (flat_layout.hpp).
+    // build_mode = mfx_params.layout_build: 0 device pipeline when the pattern is grouped, host builder
+    // otherwise; 1 host builder; 2 device pipeline or MFX_ERR_INVALID.
     int build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx, const float* val,
-              mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st);
+              mfx_memspace space, const FlatLayoutOptions& opt, int build_mode, hipStream_t st);
+    bool built_on_device() const { return built_on_device_; }
     SegStreamDev view;
     const FlatLayoutHost& layout() const { return layout_; }
     // out[input position] = stored value, for every real entry (test / debug path: mfx_ccd_get_residual)
     int unpermute(float* out, hipStream_t st);
 
 private:
+    int build_host(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx, const float* val,
+                   mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st);
+    // *done = false (and MFX_OK) when the pattern is not grouped: nothing was built
+    int build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx, const float* val,
+                     mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st, bool* done);
+    bool built_on_device_ = false;
     FlatLayoutHost layout_;
     DevBuf<uint32_t> ptr_, ptr_v_, seg_cnt_, idx_, seg_of_rank_, flags32_, hpre_, wg_panel_, perm_;
     DevBuf<float> val_;

@@ -5,7 +5,6 @@
 #include <thread>
 
 namespace mfx {
-namespace {
 
 uint32_t pick_tiles_per_span(uint64_t nnz, bool panels) {
     // Aim for ~48k spans (256 CUs x 32 resident waves x ~6 rounds) but keep a span between
@@ -18,6 +17,8 @@ uint32_t pick_tiles_per_span(uint64_t nnz, bool panels) {
     const uint64_t lo = panels ? 8 : 2;
     return (uint32_t) std::min<uint64_t>(16, std::max<uint64_t>(lo, t));
 }
+
+namespace {
 
 // Runs fn(begin, end) over [0, n) on a few host threads (plain std::thread: libmfx must not drag
 // a second OpenMP runtime into a process that already hosts torch's).

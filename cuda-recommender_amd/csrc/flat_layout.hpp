@@ -155,6 +155,9 @@ struct FlatLayoutOptions {
 // second OpenMP runtime into a process that already hosts torch's).
 void parallel_ranges_u64(uint64_t n, void (*fn)(uint64_t, uint64_t, void*), void* ctx);
 
+// span length (in 256-element tiles) chosen for `nnz` stored non-zeros; `panels`: LDS-panel layout
+uint32_t pick_tiles_per_span(uint64_t nnz, bool panels);
+
 void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, uint64_t nnz, uint32_t G,
                        const FlatLayoutOptions& opt, FlatLayoutHost* out);
 

@@ -14,12 +14,15 @@ import torch
 
 def synth_ratings_device(rows: int, cols: int, nnz: int, seed: int = 1234, device="cuda:0",
                          sigma_rows: float = 1.2, sigma_cols: float = 1.8, planted_rank: int = 8,
-                         noise: float = 0.1, test_frac: float = 0.01, row_lo: int = 0, row_hi: int = -1):
+                         noise: float = 0.1, test_frac: float = 0.01, row_lo: int = 0, row_hi: int = -1,
+                         shard=None):
     """Returns a dict of tensors on `device`: rows, cols, csr_row_ptr, csr_col_idx, csr_val,
     csc_col_ptr, csc_row_idx, csc_val, test_row, test_col, test_val, csc_of_csr (for every CSC
     position the CSR position of the same rating).  row_lo/row_hi keep only that row block
     (row ids rebased), which is how a multi-GPU shard is generated in place: every rank draws the
-    same global matrix from the same seed and keeps its rows."""
+    same global matrix from the same seed and keeps its rows.  shard = (g, G) picks block g of the G
+    nnz-balanced contiguous row blocks (the rule of mfx_partition_rows: block g starts at the first row
+    whose prefix of non-zeros reaches g/G of the total) instead of an explicit row_lo/row_hi."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     dev = torch.device(device)
@@ -61,6 +64,16 @@ def synth_ratings_device(rows: int, cols: int, nnz: int, seed: int = 1234, devic
     ti, tj, tv = values(test_keys)
     ri, rj, rv = values(train_keys)
     del train_keys, test_keys, ws, hs
+    if shard is not None and shard[1] > 1:
+        g_id, g_cnt = int(shard[0]), int(shard[1])
+        ptr = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
+        ptr[1:] = torch.cumsum(torch.bincount(ri, minlength=rows), 0)
+        total = int(ptr[-1])
+        tgt = torch.tensor([(total * q + g_cnt - 1) // g_cnt for q in (g_id, g_id + 1)], dtype=torch.int64, device=dev)
+        b = torch.searchsorted(ptr, tgt)  # lower bound, like std::lower_bound over csr_row_ptr
+        row_lo = 0 if g_id == 0 else int(b[0])
+        row_hi = rows if g_id == g_cnt - 1 else int(b[1])
+        del ptr
     if row_hi < 0:
         row_hi = rows
     if row_lo != 0 or row_hi != rows:

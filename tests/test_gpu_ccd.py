@@ -330,3 +330,67 @@ def test_sharded_solve_multi_rank_loopback(mfx, orc, medium, nshards, schedule, 
     for (Wl, Hl), rm in out:
         assert relerr(Hl, Hr) < 2e-3 and np.all(np.abs(np.array(rm) - rmse_ref) < 1e-4)
     assert all(np.array_equal(bits(out[0][0][1]), bits(o[0][1])) for o in out)  # H replicas identical
+
+
+def test_failing_shard_does_not_strand_the_others(mfx, medium):
+    """The multi-shard protocol (mfx.h, mfx_comm_agree / mfx_comm_abort): a rank whose setup fails reports it
+    through agree() and nobody enters a collective; a rank that fails later aborts the communicator and the
+    ranks already waiting inside an all-reduce come back with an error instead of hanging."""
+    import threading
+    d, k = medium, 4
+    nshards = 3
+    bounds = mfx.partition_rows(d, nshards)
+    gcnt = np.ascontiguousarray(np.diff(d.csc_col_ptr.astype(np.int64)).astype(np.uint32))
+    W0 = mfx.initial_col(k, d.rows)
+
+    # (1) setup failure on rank 1: everybody learns the worst status, nobody iterates
+    seen = [None] * nshards
+
+    def setup(r):
+        comm = mfx.Comm(None, r, nshards, 0, local_group=7001)
+        status = 0
+        try:
+            if r == 1:
+                raise mfx.MfxError("injected setup failure")
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            shard = mfx.extract_shard(d, lo, hi)
+            s = mfx.CcdSolver(shard, mfx.test_data_of(shard), _params(mfx, k, 0.05, 1, 1, 1, 1), comm=comm,
+                              global_col_nnz=gcnt, global_test_nnz=d.nnz_test)
+            s.close()
+        except mfx.MfxError:
+            status = -1
+        seen[r] = comm.agree(status)
+        comm.close()
+
+    th = [threading.Thread(target=setup, args=(r,)) for r in range(nshards)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not any(x.is_alive() for x in th) and seen == [-1, -1, -1], seen
+
+    # (2) rank 2 dies after agree: it aborts, the others' iterate() returns an error
+    res = [None] * nshards
+
+    def run(r):
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        shard = mfx.extract_shard(d, lo, hi)
+        comm = mfx.Comm(None, r, nshards, 0, local_group=7002)
+        s = mfx.CcdSolver(shard, mfx.test_data_of(shard), _params(mfx, k, 0.05, 1, 1, 1, 1), comm=comm,
+                          global_col_nnz=gcnt, global_test_nnz=d.nnz_test)
+        s.set_factors(np.ascontiguousarray(W0[:, lo:hi]))
+        assert comm.agree(0) == 0
+        if r == 2:
+            comm.abort()
+            res[r] = "aborted"
+        else:
+            try:
+                s.iterate(1)
+                res[r] = "finished"
+            except mfx.MfxError as e:
+                res[r] = "error: " + str(e)
+        s.close(); comm.close()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nshards)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not any(x.is_alive() for x in th), res
+    assert res[2] == "aborted" and all(isinstance(x, str) and x.startswith("error") and "aborted" in x for x in res[:2]), res

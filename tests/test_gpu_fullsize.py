@@ -1,5 +1,6 @@
-"""Full BASELINE.json size (configs[2]: 480189 x 17770, Z = 99 072 112, k = 64) on the GPU, checked
-through size-independent properties (the CPU oracle would need minutes here):
+"""Full BASELINE.json size (configs[2] / configs[3]: 480189 x 17770, Z = 99 072 112, k = 64) on the GPU: compared
+with the CPU oracle itself (it costs 6 s for CCD++ -t 3 and 40 s for one ALS iteration on the box's 16 host
+threads) and checked through size-independent properties:
 
   * both residual copies hold bit-identical values under the CSR<->CSC permutation (every element
     sees the same operands in the same order in the two fused passes);
@@ -171,3 +172,63 @@ def test_fullsize_follows_the_float64_trajectory(big):
     scale = float(max(W.abs().max(), H.abs().max()))
     assert float((torch.from_numpy(Wg).to(dev).to(f8) - W).abs().max()) < 1e-3 * scale
     assert float((torch.from_numpy(Hg).to(dev).to(f8) - H).abs().max()) < 1e-3 * scale
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The headline config against the ORACLE (the bit-exact restatement of the reference's ccdr1_OMP / ALS_OMP), at the
+# north star's own terms: k = 64, lambda = 0.05, per-iteration test RMSE.  Measured on MI355X (tools/
+# fullsize_oracle_check.py, committed output profiles/r02_fullsize_oracle.txt):
+#   item popularity sigma 1.8 (longest column 237 488, the real Netflix figure is 232 944):
+#       |RMSE_gpu - RMSE_oracle| = 1.6e-6, 1.28e-4, 5.1e-6 over the three outer iterations; factors 1.9e-2 of scale
+#       GPU vs the same algorithm in float64: 1.4e-8;  oracle vs float64: 1.28e-4  (the oracle's sequential fp32
+#       sums over 2e5-entry columns are the side that moves)
+#   sigma 1.12 (longest column 95 875): 4e-7, 2.4e-5, 8e-8; factors 4e-3 of scale
+# So the 1e-4 bar of the north star holds at the milder skew and is missed by 0.3e-4 at one iteration of the
+# Netflix-like one; the assertion is kept against the oracle at the tightest round bound the measurement supports
+# (2e-4 / 1e-4) -- DESIGN.md section 2 records this as a deviation.
+@pytest.mark.parametrize("sigma_cols,rmse_tol,factor_tol", [(1.8, 2e-4, 5e-2), (1.12, 1e-4, 2e-2)])
+def test_fullsize_k64_ccd_vs_oracle(sigma_cols, rmse_tol, factor_tol):
+    import torch
+    import mfx
+    from mfx import synth_torch
+    from oracle import oracle as orc
+    dev = synth_torch.synth_ratings_device(ROWS, COLS, NNZ, seed=1234, device="cuda:0", sigma_cols=sigma_cols)
+    d = synth_torch.to_rating_data(dev)
+    lam, t = 0.05, 3
+    W0 = mfx.initial_col(K, ROWS)
+    p = mfx.parameter()
+    p.k, p.lambda_, p.maxiter = K, lam, t
+    s = mfx.CcdSolver(None, None, p, device_arrays=dev)
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    W, H = s.get_factors()
+    s.close()
+    del dev
+    torch.cuda.empty_cache()
+    Wr, Hr, rmse_ref, *_ = orc.ccdr1(d, W0, K, lam, t, 1, orc.max_threads())
+    rm = np.array([r.rmse for r in rep])
+    assert np.all(np.abs(rm - rmse_ref) < rmse_tol), (rm, rmse_ref)
+    assert rmse_ref[2] < rmse_ref[1] < rmse_ref[0] and rm[2] < rm[1] < rm[0]
+    scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
+    assert np.abs(W - Wr).max() < factor_tol * scale and np.abs(H - Hr).max() < factor_tol * scale
+
+
+def test_fullsize_k64_als_vs_oracle(big):
+    """BASELINE configs[3]: one full ALS iteration at the Netflix shape, k = 64, against oracle.als (measured:
+    RMSE gap 5.8e-7, W within 5.9e-5 and H within 2.1e-4 of scale)."""
+    mfx, torch, dev = big
+    from mfx import synth_torch
+    from oracle import oracle as orc
+    d = synth_torch.to_rating_data(dev)
+    p = mfx.parameter()
+    p.k, p.lambda_ = K, 0.05
+    H0 = mfx.initial_col(COLS, K)
+    s = mfx.AlsSolver(d, mfx.test_data_of(d), p)
+    s.set_factors(H0.copy())
+    rep = s.iterate(1)
+    W, H = s.get_factors()
+    s.close()
+    Wr, Hr, rmse_ref, _ = orc.als(d, H0, K, 0.05, 1, orc.max_threads())
+    assert abs(rep[0].rmse - rmse_ref[0]) < 1e-4, (rep[0].rmse, rmse_ref)
+    scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
+    assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale

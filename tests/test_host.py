@@ -250,3 +250,26 @@ def test_one_hip_runtime_whatever_the_import_order():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert r.stdout.split()[:2] == ["1", "2"], r.stdout
+
+
+def test_bench_launches_its_own_workers():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*), they meet (gloo in this GPU-less rehearsal) and rank 0's single JSON line comes
+    back through the parent; a bare N = 1 call stays a plain single process."""
+    import json
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for n, want in ((2, 3.0), (1, 1.0)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run", "--workload", "config5"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]  # (gloo itself chats on stdout)
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d == {"dry_run": True, "n_gpus": n, "rank_sum": want, "workload": "config5"}
+    # a worker that fails makes the launcher fail
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--no-such-flag"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
