@@ -28,10 +28,16 @@ RcclApi& api() {
     static RcclApi a;
     static std::once_flag once;
     std::call_once(once, [] {
-        // A process that already imported torch has its bundled librccl.so.1 mapped; asking for
-        // the SONAME reuses that copy instead of mapping a second RCCL next to it.
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // One RCCL per process, like one HIP runtime (mfx/_lib.py): PyTorch-ROCm bundles its own
+        // librccl under /opt/rocm's SONAME.  A process that already imported torch has that copy mapped
+        // and asking for the SONAME reuses it; a process that will import torch LATER must get the same
+        // file now -- its path arrives in MFX_RCCL_PATH (set by the Python binding when torch is installed)
+        // -- or torch would map a second RCCL next to ours (seen: heap corruption at interpreter exit).
+        // RTLD_LOCAL: the symbols are looked up with dlsym, nothing else in the process should bind to them.
+        const char* hint = getenv("MFX_RCCL_PATH");
+        for (const char* name : {hint, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (!name || !*name) continue;
+            a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (a.handle) break;
         }
         if (!a.handle) {

@@ -148,10 +148,15 @@ def _pin_one_hip_runtime() -> None:
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
         _HIP_RUNTIME = cand
+        # the same for RCCL, lazily: libmfx dlopens it on first use and takes this path first (csrc/comm.cpp)
+        rccl = os.path.join(libdir, "librccl.so")
+        if os.path.exists(rccl):
+            os.environ.setdefault("MFX_RCCL_PATH", rccl)
 
 
 def lib() -> C.CDLL:
