@@ -293,11 +293,17 @@ def main() -> None:
         "ccd_flat_resid": 12.0 * Z + flags + 4.0 * (m + n),
         "ccd_wave_sweep": 8.0 * Z + 4.0 * (m + n) + 8.0 * min(m, n),
         "ccd_wave_resid": 12.0 * Z + 4.0 * (m + n),
+        # scatter layout (hyper-sparse shards): the same contract as the fused passes they replace
+        "ccd_scatter_v_pass": 12.0 * Z + flags + 8.0 * m + 8.0 * n + 8.0 * n,
+        "ccd_scatter_u_pass": 12.0 * Z + flags + 16.0 * n + 8.0 * m + 8.0 * m,
+        "ccd_scatter_sweep": 8.0 * Z + flags + 4.0 * max(m, n) + 8.0 * min(m, n),
     }
     # bytes the LDS-panel kernels physically stream per non-zero: 16-bit local index + fp32 value read
     # + fp32 value written (the contract figure above keeps SURVEY 8d's 32-bit index)
     phys = {"ccd_fused_csc_pass": 10.0 * Z + 2 * flags, "ccd_fused_csr_pass": 10.0 * Z + 2 * flags,
-            "ccd_flat_sweep": 6.0 * Z + 2 * flags, "ccd_flat_resid": 10.0 * Z + 2 * flags}
+            "ccd_flat_sweep": 6.0 * Z + 2 * flags, "ccd_flat_resid": 10.0 * Z + 2 * flags,
+            # scatter: 16-bit local index + 32-bit segment id + fp32 value read + written
+            "ccd_scatter_v_pass": 14.0 * Z, "ccd_scatter_u_pass": 14.0 * Z, "ccd_scatter_sweep": 10.0 * Z}
     roofline = None
     dom = None
     if ktimes:
@@ -321,7 +327,8 @@ def main() -> None:
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
                         "algorithmic_bytes_per_launch": int(alg[dom]),
-                        "streamed_bytes_per_launch": int(phys[dom]) if (dom in phys and layout["csr" if "csr" in dom else "csc"]["kind"] == "lds") else int(alg[dom]),
+                        "streamed_bytes_per_launch": int(phys[dom]) if (dom in phys and (
+                            "scatter" in dom or layout["csr" if "csr" in dom else "csc"]["kind"] == "lds")) else int(alg[dom]),
                         "as_written_equiv_frac": round(a.k * (48 + 16 * a.inner) * nnz_global /
                                                        (elapsed / a.steps) / 1e9 / (HBM_PEAK_GBS * world), 4)}
     kernels = {kn: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1]),
@@ -346,11 +353,12 @@ def main() -> None:
         s2.iterate(1, with_rmse=False)
         kt2 = s2.kernel_times()
         s2.close()
-        if "ccd_flat_sweep" in kt2:
-            secs, launches = kt2["ccd_flat_sweep"]
+        sweep_name = "ccd_flat_sweep" if "ccd_flat_sweep" in kt2 else "ccd_scatter_sweep"
+        if sweep_name in kt2:
+            secs, launches = kt2[sweep_name]
             avg = secs / max(1, launches)
             b_r1 = 8.0 * Z + 0.5 * ((4.0 * (n + 1) + 4.0 * m + 4.0 * n) + (4.0 * (m + 1) + 4.0 * n + 4.0 * m))  # mean of the two sides
-            rank_one = {"kernel": "ccd_flat_sweep", "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
+            rank_one = {"kernel": sweep_name, "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
                         "algorithmic_bytes_per_launch": int(b_r1), "achieved": round(b_r1 / avg / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(b_r1 / avg / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "standalone v-/u-sweep launches of one outer iteration at T = 2 (inner iteration 2)"}

@@ -773,12 +773,18 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
     for (int it = 0; it < n_iter; ++it) {
         MFX_HIP(hipMemsetAsync(spd_fail_.get(), 0, sizeof(uint32_t), st_));
         MFX_HIP(hipEventRecord(ev_[0], st_));
-        MFX_TRY(als_half_launch(rows_, H_.get(), n_, W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, ws_.get(),
-                                spd_fail_.get(), st_));
+        if (p_.schedule == 0)  // as written: the reference's arithmetic, bit for bit (als_exact.hip)
+            MFX_TRY(als_half_exact_launch(rows_, H_.get(), W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, spd_fail_.get(), st_));
+        else
+            MFX_TRY(als_half_launch(rows_, H_.get(), n_, W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, ws_.get(),
+                                    spd_fail_.get(), st_));
         if (comm_) MFX_TRY(exchange(W_.get(), row_bounds_));
         MFX_HIP(hipEventRecord(ev_[1], st_));
-        MFX_TRY(als_half_launch(cols_, W_.get(), m_, H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, ws_.get(),
-                                spd_fail_.get(), st_));
+        if (p_.schedule == 0)
+            MFX_TRY(als_half_exact_launch(cols_, W_.get(), H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, spd_fail_.get(), st_));
+        else
+            MFX_TRY(als_half_launch(cols_, W_.get(), m_, H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, ws_.get(),
+                                    spd_fail_.get(), st_));
         if (comm_) MFX_TRY(exchange(H_.get(), col_bounds_));
         MFX_HIP(hipEventRecord(ev_[2], st_));
         double rmse = 0.0, sum = 0.0;
@@ -878,7 +884,7 @@ int als_gramian_op(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const floa
 }
 
 int als_half_op(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
-                int64_t nrows_x, const float* X, float* Y, int64_t k, float lambda, int device) {
+                int64_t nrows_x, const float* X, float* Y, int64_t k, float lambda, int variant, int device) {
     MFX_REQUIRE(k <= 128, "ALS: rank k = %lld not supported (1 <= k <= 128)", (long long) k);
     MFX_TRY(use_device(device));
     OpStream os;
@@ -890,7 +896,8 @@ int als_half_op(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* 
     MFX_TRY(dY.alloc_zero((size_t) nseg * k, os.st));
     MFX_TRY(ws.alloc(std::max<size_t>(1, als_ws_floats(h.nslots, (uint32_t) k))));
     MFX_TRY(fail_cnt.alloc_zero(1, os.st));
-    MFX_TRY(als_half_launch(h, dX.get(), (uint32_t) nrows_x, dY.get(), (uint32_t) k, lambda, ws.get(), fail_cnt.get(), os.st));
+    if (variant == 0) MFX_TRY(als_half_exact_launch(h, dX.get(), dY.get(), (uint32_t) k, lambda, fail_cnt.get(), os.st));
+    else MFX_TRY(als_half_launch(h, dX.get(), (uint32_t) nrows_x, dY.get(), (uint32_t) k, lambda, ws.get(), fail_cnt.get(), os.st));
     MFX_HIP(hipMemcpyAsync(Y, dY.get(), sizeof(float) * (size_t) nseg * k, hipMemcpyDeviceToHost, os.st));
     MFX_HIP(hipStreamSynchronize(os.st));
     return MFX_OK;

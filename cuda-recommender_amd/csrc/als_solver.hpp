@@ -80,10 +80,15 @@ int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y,
 // floats of workspace needed for `nslots` partial slots at rank k
 size_t als_ws_floats(uint32_t nslots, uint32_t k);
 
+// The half-sweep "as written" (als_exact.hip): the reference's arithmetic in its order, bit for bit.
+int als_half_exact_launch(const AlsHalf& h, const float* X, float* Y, uint32_t k, float lambda, uint32_t* spd_fail, hipStream_t st);
+// inverseMatrix_CholeskyMethod on one k x k matrix (host pointers), same arithmetic
+int als_inverse_op(int64_t k, const float* A, float* Ainv, int device);
+
 int als_gramian_op(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const float* X, int64_t k, float* A,
                    int device);
 int als_half_op(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
-                int64_t nrows_x, const float* X, float* Y, int64_t k, float lambda, int device);
+                int64_t nrows_x, const float* X, float* Y, int64_t k, float lambda, int variant, int device);
 
 }  // namespace mfx
 

@@ -362,14 +362,21 @@ int mfx_als_gramian(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const flo
     });
 }
 
+int mfx_als_inverse(int64_t k, const float* A, float* Ainv, int device) {
+    return guarded("mfx_als_inverse", [&]() -> int {
+        MFX_REQUIRE(A && Ainv, "mfx_als_inverse: null argument");
+        return als_inverse_op(k, A, Ainv, device);
+    });
+}
+
 int mfx_als_half(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
-                 int64_t nrows_x, const float* X, float* Y, int64_t k, float lambda, int device) {
+                 int64_t nrows_x, const float* X, float* Y, int64_t k, float lambda, int variant, int device) {
     return guarded("mfx_als_half", [&]() -> int {
         MFX_REQUIRE(nseg > 0 && nnz >= 0 && ptr && X && Y && k > 0 && nrows_x > 0, "mfx_als_half: bad argument");
         MFX_REQUIRE(nnz == 0 || (idx && val), "mfx_als_half: null idx / val with nnz > 0");
         MFX_REQUIRE(nseg < (int64_t) 0xFFFFFFFFll && nrows_x < (int64_t) 0xFFFFFFFFll && nnz < (int64_t) 0xFFFF0000ll,
                     "mfx_als_half: sizes exceed the 32-bit index range");
-        return als_half_op(nseg, nnz, ptr, idx, val, nrows_x, X, Y, k, lambda, device);
+        return als_half_op(nseg, nnz, ptr, idx, val, nrows_x, X, Y, k, lambda, variant, device);
     });
 }
 

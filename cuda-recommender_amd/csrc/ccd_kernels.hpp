@@ -39,6 +39,13 @@ struct SegStreamDev {
     const uint32_t* seg_of_rank = nullptr;     // [nne] real segment id
     const uint32_t* wg_panel = nullptr;        // [nspans/spans_per_wg]
     const uint32_t* perm = nullptr;            // [padded nnz] input position, ~0u for padding; nullptr: SegStreamStore::unpermute knows
+    // scatter layout (ccd_scatter.hip; hyper-sparse orientations): the panel-major order of the LDS-panel
+    // layout, read the other way round -- idx16 is the local index of the REDUCED dimension, segid the id of
+    // the streamed one; no head flags / ranks / partials
+    bool scatter = false;
+    const uint32_t* segid = nullptr;           // [padded nnz] segment of every stored element (pad: 0)
+    unsigned long long* wgacc = nullptr;       // [workgroups][2 * panel_rows] fixed-point (g, h) slabs
+    const uint32_t* wg_lo = nullptr;           // [npanels + 1] first workgroup of every panel
     // reduction scratch written by the flat kernels
     float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
     float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run
@@ -56,6 +63,19 @@ enum FlatMode : int {
 // Flat-stream pass over `s`.  gather/perseg element types depend on `mode` (see FlatMode).
 int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg,
                 int add, hipStream_t st);
+
+// Scatter passes (ccd_scatter.hip).  `s` is the store of the orientation being STREAMED; results are per
+// index of its gathered ("local") dimension.  slice_src: operands of the local dimension; global_op:
+// operands of the streamed dimension (indexed by segment id).
+enum ScatterMode : int {
+    SM_V = 0,      // slice float2 B, streamed float2 A: val = (val - A.x*B.x) + A.y*B.y ; g += A.y*val ; h += A.y^2
+    SM_U = 1,      // slice float2 D, streamed float4 C: val = (val - C.x*D.x) + C.y*D.y ; g += C.z*val ; h += C.z^2
+    SM_SWEEP = 2,  // streamed float x: g += x*val ; h += x*x
+    SM_RESID = 3,  // slice float y, streamed float x: val (+/-)= y*x
+};
+int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st);
+// slabs of a scatter pass -> dense gh[0..G) = g, gh[G..2G) = h over the local dimension (G = s.gather_len)
+int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st);
 
 // Wave-per-segment kernels (plain layout only: they walk the input-order arrays).
 int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, float* h_dense,

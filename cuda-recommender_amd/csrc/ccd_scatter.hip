@@ -1,0 +1,229 @@
+// ccd_scatter.hip -- CCD++ passes for HYPER-SPARSE orientations (config 5's shard: 1.25 M x 1 M with
+// 125 M ratings, ~100 entries per row / column, density 1e-4).
+//
+// Why another kernel.  The flat-stream kernel (ccd_kernels.hip) reduces per segment and gathers the
+// other operand; its gather is served from LDS only if the gathered dimension is cut into LDS-sized
+// panels, and at this density a (panel, segment) pair holds 0.6 entries: the segments are shredded.
+// Round 1 therefore fell back to L2-sized "cache panels" with per-lane global gathers, which the
+// texture path serves at ~85 G gathers/s -- 0.2 of the HBM roofline (profiles/r02_ubench_scatter.txt,
+// "RANDOM global row operand": 1.5 ms per 126 M entries).
+//
+// What this kernel does instead: SWAP THE ROLES.  A pass that needs the sums over COLUMNS streams the
+// ROW-major copy (and vice versa), stored panel-major over the columns:
+//   * the panel's columns are local (16-bit index): their operands AND their (g, h) accumulators sit in
+//     LDS (24 B per column, 6144 columns per workgroup);
+//   * inside a panel the entries keep the copy's row-major order, so the row operand is an ASCENDING,
+//     nearly sequential global read (a wave's 256 entries span ~400 rows = ~25 cache lines instead of
+//     256 random ones) -- the row id of every entry is stored explicitly (4 B/nnz: 14 B/nnz streamed);
+//   * the reduction is a scatter-add into the LDS accumulators.  It is made ORDER-INDEPENDENT, hence
+//     bitwise reproducible, by accumulating the fp32 contributions in 64-bit fixed point (ds_add_u64,
+//     scale 2^36: exact for |x| < 1.3e8, resolution 1.5e-11; an fp32 sum of n such terms is off by
+//     ~6e-8 * |sum| * sqrt(n), the fixed-point one by ~1e-11 * sqrt(n)).  LDS fp32 atomics would be both
+//     non-deterministic and 4x slower (same profile: 1.39 ms vs 0.34 ms).
+// Every workgroup flushes its accumulators to its own slab; k_scatter_combine adds the slabs of a panel
+// (integers: any order gives the same bits) and converts to the dense fp32 (g, h) that the ordinary
+// finalize / all-reduce path takes.  Measured (microbenchmark of exactly this shape): 0.40-0.42 ms per
+// pass against 0.93 ms for cache panels.
+//
+// The per-element arithmetic is the reference's (unfused multiply, subtract, multiply, add) as in the flat
+// kernel, so both residual copies keep holding bit-identical values whichever kernel updates them.
+#include "ccd_kernels.hpp"
+
+#include <mutex>
+
+namespace mfx {
+namespace {
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kScatBlock = 1024;  // 16 wavefronts, one workgroup per CU (the LDS is the limit)
+
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+
+// fp32 -> 64-bit fixed point (two's complement), scale 2^36: exact for every fp32 with |x| < 2^27
+__device__ __forceinline__ unsigned long long to_fixed(float x) {
+    return (unsigned long long) (long long) ((double) x * 68719476736.0);
+}
+
+struct ScatterArgs {
+    const uint16_t* lidx;     // [padded] local index inside the panel (pad: panel_rows)
+    const uint32_t* segid;    // [padded] id of the streamed dimension (row of a row-major copy), ascending inside a panel
+    float* val;               // [padded] residual copy
+    const uint32_t* wg_panel; // [workgroups]
+    uint32_t tiles_per_span, panel_rows, local_len;
+    const void* slice_src;    // operands of the local dimension, [local_len]
+    const void* global_op;    // operands of the streamed dimension, indexed by segid
+    unsigned long long* wgacc;  // [workgroups][2 * panel_rows] slabs
+    int add;
+};
+
+template <int MODE> struct ScatTraits;
+// the two fused passes: slice (prev_new, cur_old) of the local dimension; streamed operand float2 (V) or float4 (U)
+template <> struct ScatTraits<SM_V>     { using S = float2; using G = float2; static constexpr bool kSlice = true,  kAcc = true,  kWrite = true; };
+template <> struct ScatTraits<SM_U>     { using S = float2; using G = float4; static constexpr bool kSlice = true,  kAcc = true,  kWrite = true; };
+template <> struct ScatTraits<SM_SWEEP> { using S = float;  using G = float;  static constexpr bool kSlice = false, kAcc = true,  kWrite = false; };
+template <> struct ScatTraits<SM_RESID> { using S = float;  using G = float;  static constexpr bool kSlice = true,  kAcc = false, kWrite = true; };
+
+__host__ __device__ constexpr size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+template <int MODE>
+__host__ __device__ size_t scat_slice_bytes(uint32_t pr) { return ScatTraits<MODE>::kSlice ? align16(((size_t) pr + 1) * sizeof(typename ScatTraits<MODE>::S)) : 0; }
+template <int MODE>
+__host__ __device__ size_t scat_lds_bytes(uint32_t pr) { return scat_slice_bytes<MODE>(pr) + (ScatTraits<MODE>::kAcc ? ((size_t) pr + 1) * 16 : 0); }
+
+template <int MODE>
+__global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
+    using TR = ScatTraits<MODE>;
+    using S = typename TR::S;
+    using G = typename TR::G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    S* __restrict__ slice = reinterpret_cast<S*>(lds_raw);
+    unsigned long long* __restrict__ acc = reinterpret_cast<unsigned long long*>(lds_raw + scat_slice_bytes<MODE>(a.panel_rows));
+    const uint32_t pr = a.panel_rows;
+    const uint32_t panel = a.wg_panel[blockIdx.x];
+    const uint32_t gbase = panel * pr;
+    const uint32_t cnt = a.local_len - gbase < pr ? a.local_len - gbase : pr;
+    if constexpr (TR::kSlice) {
+        const S* __restrict__ src = static_cast<const S*>(a.slice_src);
+        // slots cnt .. pr (the tail of a short last panel and the padding slot) hold zeros: padding entries
+        // then keep their stored 0 and contribute exact zeros
+        for (uint32_t i = threadIdx.x; i <= pr; i += kScatBlock) slice[i] = i < cnt ? src[gbase + i] : S{};
+    }
+    if constexpr (TR::kAcc)
+        for (uint32_t i = threadIdx.x; i < 2 * (pr + 1); i += kScatBlock) acc[i] = 0ull;
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t span = blockIdx.x * (kScatBlock / 64) + (threadIdx.x >> 6);
+    const uint64_t start = (uint64_t) span * a.tiles_per_span * 256;
+    const u16x4* __restrict__ l4 = reinterpret_cast<const u16x4*>(a.lidx + start) + lane;
+    const u32x4* __restrict__ s4 = reinterpret_cast<const u32x4*>(a.segid + start) + lane;
+    f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
+    const G* __restrict__ gop = static_cast<const G*>(a.global_op);
+    u16x4 ln = __builtin_nontemporal_load(l4);
+    u32x4 sn = __builtin_nontemporal_load(s4);
+    f32x4 vn = __builtin_nontemporal_load(v4);
+    for (uint32_t t = 0; t < a.tiles_per_span; ++t) {
+        const u16x4 li = ln;
+        const u32x4 si = sn;
+        const f32x4 v = vn;
+        if (t + 1 < a.tiles_per_span) {
+            ln = __builtin_nontemporal_load(l4 + (t + 1) * 64);
+            sn = __builtin_nontemporal_load(s4 + (t + 1) * 64);
+            vn = __builtin_nontemporal_load(v4 + (t + 1) * 64);
+        }
+        G gp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gp[e] = gop[si[e]];  // ascending inside a panel: a few cache lines per wave
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t l = li[e];
+            float gc, hc;
+            if constexpr (MODE == SM_V) {
+                const float2 sp = slice[l];
+                o[e] = add_rn(sub_rn(v[e], mul_rn(gp[e].x, sp.x)), mul_rn(gp[e].y, sp.y));
+                gc = gp[e].y * o[e];
+                hc = gp[e].y * gp[e].y;
+            } else if constexpr (MODE == SM_U) {
+                const float2 sp = slice[l];
+                o[e] = add_rn(sub_rn(v[e], mul_rn(gp[e].x, sp.x)), mul_rn(gp[e].y, sp.y));
+                gc = gp[e].z * o[e];
+                hc = gp[e].z * gp[e].z;
+            } else if constexpr (MODE == SM_SWEEP) {
+                o[e] = v[e];
+                gc = gp[e] * v[e];
+                hc = gp[e] * gp[e];
+            } else {
+                const float prod = mul_rn(slice[l], gp[e]);
+                o[e] = a.add ? add_rn(v[e], prod) : sub_rn(v[e], prod);
+                gc = 0.f; hc = 0.f;
+            }
+            if constexpr (TR::kAcc) {
+                atomicAdd(&acc[2 * l], to_fixed(gc));
+                atomicAdd(&acc[2 * l + 1], to_fixed(hc));
+            }
+        }
+        if constexpr (TR::kWrite) __builtin_nontemporal_store(o, v4 + t * 64);
+    }
+    if constexpr (TR::kAcc) {
+        __syncthreads();
+        unsigned long long* __restrict__ dst = a.wgacc + (size_t) blockIdx.x * 2 * pr;
+        for (uint32_t i = threadIdx.x; i < 2 * pr; i += kScatBlock) dst[i] = acc[i];
+    }
+}
+
+// gh[c] = g, gh[G + c] = h of local-dimension index c: the slabs of its panel's workgroups added as integers
+__global__ __launch_bounds__(256) void k_scatter_combine(uint32_t G, uint32_t pr, const uint32_t* __restrict__ wg_lo,
+                                                         const unsigned long long* __restrict__ wgacc, float* __restrict__ gh) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= G) return;
+    const uint32_t p = c / pr, l = c - p * pr;
+    unsigned long long g = 0, h = 0;
+    for (uint32_t w = wg_lo[p]; w < wg_lo[p + 1]; ++w) {
+        const unsigned long long* s = wgacc + (size_t) w * 2 * pr + 2 * l;
+        g += s[0];
+        h += s[1];
+    }
+    constexpr double inv = 1.0 / 68719476736.0;
+    gh[c] = (float) ((double) (long long) g * inv);
+    gh[G + c] = (float) ((double) (long long) h * inv);
+}
+
+template <int MODE>
+int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, hipStream_t st) {
+    const size_t lds = scat_lds_bytes<MODE>(s.panel_rows);
+    MFX_REQUIRE(lds <= 160 * 1024, "scatter layout: %u local entries do not fit LDS", s.panel_rows);
+    if (lds > 48 * 1024) {  // a per-device attribute of the kernel: set once per (instantiation, device)
+        static std::mutex m;
+        static size_t set_bytes[64] = {};
+        int dev = 0;
+        MFX_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(m);
+        if (dev < 0 || dev >= 64 || lds > set_bytes[dev]) {
+            MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scatter<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            if (dev >= 0 && dev < 64) set_bytes[dev] = lds;
+        }
+    }
+    hipLaunchKernelGGL(k_scatter<MODE>, dim3(s.nspans / s.spans_per_wg), dim3(kScatBlock), lds, st, a);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+}  // namespace
+
+int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st) {
+    MFX_REQUIRE(s.scatter && s.spans_per_wg == kScatBlock / 64, "launch_scatter: not a scatter layout");
+    ScatterArgs a;
+    a.lidx = s.idx16; a.segid = s.segid; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
+    a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;
+    a.add = add;
+    switch (mode) {
+        case SM_V: return launch_scatter_t<SM_V>(s, a, st);
+        case SM_U: return launch_scatter_t<SM_U>(s, a, st);
+        case SM_SWEEP: return launch_scatter_t<SM_SWEEP>(s, a, st);
+        case SM_RESID: return launch_scatter_t<SM_RESID>(s, a, st);
+        default: return fail(MFX_ERR_INVALID, "launch_scatter: bad mode %d", (int) mode);
+    }
+}
+
+int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st) {
+    if (s.gather_len == 0) return MFX_OK;
+    hipLaunchKernelGGL(k_scatter_combine, dim3((s.gather_len + 255) / 256), dim3(256), 0, st, s.gather_len, s.panel_rows, s.wg_lo, s.wgacc, gh);
+    MFX_HIP(hipGetLastError());
+    return MFX_OK;
+}
+
+}  // namespace mfx

@@ -49,6 +49,7 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
         MFX_REQUIRE(build_mode != 2, "layout_build = 2: the pattern is not grouped (some segment visits a panel more than "
                                      "once; sort the indices inside every row / column) -- the device builder cannot take it");
     }
+    MFX_REQUIRE(!opt.scatter, "the scatter layout is built by the device pipeline only (pattern not grouped, or layout_build = 1)");
     return build_host(nseg, nnz, G, ptr, idx, val, space, opt, st);
 }
 
@@ -140,8 +141,10 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     // stored order
     if (in.idx16) MFX_TRY(idx16_.alloc(padded)); else MFX_TRY(idx_.alloc(padded));
     MFX_TRY(val_.alloc(padded));
+    if (opt.scatter) MFX_TRY(segid_.alloc(padded));
     MFX_TRY(lk_place(in, padded, ptr_v_.get(), first_q_dev_.get(), cnt.get(), flags32_.get(), hpre_.get(), v_of_rank.get(),
-                     in.idx16 ? static_cast<void*>(idx16_.get()) : static_cast<void*>(idx_.get()), val_.get(), st));
+                     in.idx16 ? static_cast<void*>(idx16_.get()) : static_cast<void*>(idx_.get()), val_.get(),
+                     opt.scatter ? segid_.get() : nullptr, st));
     MFX_TRY(dmax.alloc_zero(1, st));
     MFX_TRY(lk_max_wg_ranks(hpre_.get(), nwords, (size_t) (chunk / 32), dmax.get(), st));
     uint32_t max_wg_ranks = 0;
@@ -171,10 +174,22 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     MFX_TRY(wg_panel_.alloc(wg_panel.empty() ? 1 : wg_panel.size()));
     MFX_TRY(wg_panel_.upload(wg_panel.data(), wg_panel.size(), MFX_HOST, st));
     MFX_TRY(panel_end_dev_.alloc(P)); MFX_TRY(panel_end_dev_.upload(real_end.data(), P, MFX_HOST, st));
-    MFX_TRY(part_.alloc_zero(nne ? nne : 1, st));
-    MFX_TRY(carry_.alloc_zero(nspans, st));
+    std::vector<uint32_t> wg_lo;
+    if (opt.scatter) {  // slabs of the workgroups + first workgroup of every panel; no partials / carries
+        MFX_REQUIRE(opt.panel_rows && lds && spans_per_wg == 16, "scatter layout needs LDS panels and 16-span workgroups");
+        const uint32_t nwg = nspans / spans_per_wg;
+        wg_lo.assign((size_t) P + 1, nwg);
+        for (uint32_t w = nwg; w-- > 0;) wg_lo[wg_panel[w]] = w;
+        for (uint32_t p = P; p-- > 0;) if (wg_lo[p] > wg_lo[p + 1]) wg_lo[p] = wg_lo[p + 1];  // a panel without workgroups
+        MFX_TRY(wg_lo_.alloc(wg_lo.size())); MFX_TRY(wg_lo_.upload(wg_lo.data(), wg_lo.size(), MFX_HOST, st));
+        MFX_TRY(wgacc_.alloc((size_t) nwg * 2 * opt.panel_rows));
+    } else {
+        MFX_TRY(part_.alloc_zero(nne ? nne : 1, st));
+        MFX_TRY(carry_.alloc_zero(nspans, st));
+    }
     MFX_HIP(hipStreamSynchronize(st));  // host vectors behind the uploads, temporaries behind the kernels
     tm.lap("dev: placement + rest");
+    if (opt.scatter) { flags32_.release(); hpre_.release(); rank_code_.release(); seg_of_rank_.release(); }
 
     layout_ = FlatLayoutHost();  // scalars only: the arrays live in HBM
     layout_.nseg = nseg; layout_.gather_len = G; layout_.npanels = P; layout_.panel_rows = opt.panel_rows; layout_.lds = lds;
@@ -191,6 +206,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     view.seg_of_rank = seg_of_rank_.get(); view.max_wg_ranks = max_wg_ranks;
     view.wg_panel = wg_panel_.get(); view.perm = nullptr; view.part = part_.get();
     view.carry = carry_.get();
+    view.scatter = opt.scatter; view.segid = segid_.get(); view.wgacc = wgacc_.get(); view.wg_lo = wg_lo_.get();
     *done = true;
     return MFX_OK;
 }
@@ -372,13 +388,26 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
         return o;
     }
     o.panel_rows = pr;
+    // A workgroup stages the per-segment operands of the ranks it touches in an LDS window of 1024 entries
+    // (ccd_kernels.hip); ranks beyond it fall back to two dependent global loads each.  Keep a workgroup's
+    // chunk (spans_per_wg spans) at ~0.85 x 1024 virtual segments of mean length: found at Z = 9.9e8
+    // (4.8 M x 17 770, 41 entries per (panel, row) pair), where 16-tile spans put 1 600 ranks in every
+    // chunk and the CSR pass fell from 0.79 to 0.57 of the HBM roofline.
+    if (o.tiles_per_span == 0 && npanels >= 1) {
+        const double chunk_cap = 0.85 * 1024.0 * std::max(1.0, mean_vseg);
+        uint32_t cap = (uint32_t) std::min<double>(16.0, chunk_cap / ((double) o.spans_per_wg * kTileElems));
+        cap &= ~1u;  // spans are consumed in tile pairs
+        const uint32_t want = pick_tiles_per_span(nnz, true);
+        o.tiles_per_span = std::max<uint32_t>(2u, std::min<uint32_t>(want, std::max<uint32_t>(2u, cap)));
+    }
     return o;
 }
 
 // ------------------------------------------------------------------------------------------------
 static const char* kKernelNames[KernelProfiler::K_COUNT] = {
     "ccd_fused_csc_pass", "ccd_fused_csr_pass", "ccd_flat_sweep", "ccd_flat_resid", "ccd_finalize",
-    "ccd_combine_dense", "ccd_pack", "test_rmse", "rccl_allreduce", "ccd_wave_sweep", "ccd_wave_resid"};
+    "ccd_combine_dense", "ccd_pack", "test_rmse", "rccl_allreduce", "ccd_wave_sweep", "ccd_wave_resid",
+    "ccd_scatter_v_pass", "ccd_scatter_u_pass", "ccd_scatter_sweep", "ccd_scatter_resid", "ccd_scatter_combine"};
 
 const char* KernelProfiler::name(int id) { return id >= 0 && id < K_COUNT ? kKernelNames[id] : "?"; }
 
@@ -477,37 +506,21 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     m_ = (uint32_t) R->rows; n_ = (uint32_t) R->cols; k_ = p->k; nnz_ = (uint64_t) R->nnz;
     prof_.enable(p->profile != 0 || p->schedule == 0);
 
-    // wave-per-segment kernels (schedule 0, variant 0) walk the input-order arrays
+    // Layouts.  Hyper-sparse shapes (LDS-sized panels would leave < 8 entries per (panel, segment) pair on
+    // either side, so that side would fall back to L2 "cache panels") take the scatter layout on BOTH sides
+    // (ccd_scatter.hip); kernel_variant = 2 forces it, panel_rows != 0 or kernel_variant = 0 rule it out.
     const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
-    // CSC side gathers the float2 pack (u_prev, u_cur) by row; CSR side the float4 pack by column
-    // The two orientations are independent: build them side by side (the serial stretches of one
-    // overlap the parallel passes of the other).  Error text is thread-local, so carry it across.
-    int rc_csr = MFX_OK;
-    std::string err_csr;
-    // (host allocations of several GB can fail: no exception may leave a thread or cross the C ABI;
-    // ThreadGang runs the job inline when no thread can be started and joins in its destructor)
-    ThreadGang csr_gang;
-    csr_gang.run([&] {
-        try {
-            rc_csr = use_device(device_);
-            if (rc_csr == MFX_OK)
-                rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space,
-                                    choose_layout(*p, m_, nnz_, n_, sizeof(float4), need_plain), p->layout_build, st_);
-        } catch (const std::exception& ex) {
-            rc_csr = fail(MFX_ERR_ALLOC, "building the CSR copy failed: %s", ex.what());
-        }
-        if (rc_csr != MFX_OK) err_csr = last_error();
-    });
-    int rc_csc;
-    try {
-        rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space,
-                            choose_layout(*p, n_, nnz_, m_, sizeof(float2), need_plain), p->layout_build, st_);
-    } catch (const std::exception& ex) {
-        rc_csc = fail(MFX_ERR_ALLOC, "building the CSC copy failed: %s", ex.what());
+    bool want_scatter = p->kernel_variant == 2;
+    if (!want_scatter && !need_plain && p->panel_rows == 0 && p->layout_build != 1) {
+        const FlatLayoutOptions a = choose_layout(*p, m_, nnz_, n_, sizeof(float4), false), b = choose_layout(*p, n_, nnz_, m_, sizeof(float2), false);
+        want_scatter = (a.panel_rows && !a.lds) || (b.panel_rows && !b.lds);
     }
-    csr_gang.wait();
-    if (rc_csc != MFX_OK) return rc_csc;
-    if (rc_csr != MFX_OK) { last_error() = err_csr; return rc_csr; }
+    int rc = build_stores(R, p, space, want_scatter);
+    if (rc != MFX_OK && want_scatter && p->kernel_variant != 2) {  // e.g. unsorted indices: the ordinary layouts take anything
+        csr_ = SegStreamStore(); csc_ = SegStreamStore();
+        rc = build_stores(R, p, space, false);
+    }
+    MFX_TRY(rc);
 
     MFX_TRY(W_.alloc_zero((size_t) k_ * m_, st_));
     MFX_TRY(H_.alloc_zero((size_t) k_ * n_, st_));
@@ -543,6 +556,48 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     return MFX_OK;
 }
 
+// Both orientations, side by side (the serial stretches of one overlap the parallel passes / transfers of
+// the other).  Error text is thread-local, so it is carried across.
+int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace space, bool scatter) {
+    const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
+    auto options = [&](uint32_t nseg, uint32_t G, uint32_t elem_bytes) {
+        if (!scatter) return choose_layout(*p, nseg, nnz_, G, elem_bytes, need_plain);
+        FlatLayoutOptions o;  // scatter: 24 B of LDS per local index (operand pair + two 64-bit accumulators)
+        o.scatter = true; o.lds = true; o.spans_per_wg = 16;
+        o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : 6144u, std::max<uint32_t>(G, 1u));
+        o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : 0;
+        return o;
+    };
+    scatter_ = scatter;
+    int rc_csr = MFX_OK;
+    std::string err_csr;
+    // (host allocations of several GB can fail: no exception may leave a thread or cross the C ABI;
+    // ThreadGang runs the job inline when no thread can be started and joins in its destructor)
+    ThreadGang csr_gang;
+    csr_gang.run([&] {
+        try {
+            rc_csr = use_device(device_);
+            if (rc_csr == MFX_OK)
+                rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, options(m_, n_, sizeof(float4)),
+                                    scatter ? 2 : p->layout_build, st_);
+        } catch (const std::exception& ex) {
+            rc_csr = fail(MFX_ERR_ALLOC, "building the CSR copy failed: %s", ex.what());
+        }
+        if (rc_csr != MFX_OK) err_csr = last_error();
+    });
+    int rc_csc;
+    try {
+        rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, options(n_, m_, sizeof(float2)),
+                            scatter ? 2 : p->layout_build, st_);
+    } catch (const std::exception& ex) {
+        rc_csc = fail(MFX_ERR_ALLOC, "building the CSC copy failed: %s", ex.what());
+    }
+    csr_gang.wait();
+    if (rc_csc != MFX_OK) return rc_csc;
+    if (rc_csr != MFX_OK) { last_error() = err_csr; return rc_csr; }
+    return MFX_OK;
+}
+
 int CcdSolver::set_factors(const float* W, const float* H, mfx_memspace space) {
     MFX_REQUIRE(W, "mfx_ccd_set_factors: W is required");
     MFX_REQUIRE(oiter_ == 0, "factors can only be set before the first iteration");
@@ -573,7 +628,53 @@ int CcdSolver::finalize_cols(const FinalizeArgs& base) {
     return MFX_OK;
 }
 
+// Slabs of the scatter pass that just ran -> dense (g, h) -> all-reduce over the shards (column side) ->
+// the ordinary finalize from a dense buffer.  `cols`: the sums are over columns (they came from csr_).
+int CcdSolver::scatter_finalize(bool cols, const FinalizeArgs& base) {
+    SegStreamStore& src = cols ? csr_ : csc_;  // the store that was streamed; results are per its local dimension
+    float* gh = cols ? gh_cols_.get() : gh_rows_.get();
+    PROF(KernelProfiler::K_SCAT_COMBINE, launch_scatter_combine(src.view, gh, st_));
+    FinalizeArgs f = base;
+    f.gh_dense = gh;
+    f.cnt_override = (cols ? csc_ : csr_).view.seg_cnt;  // |Omega| of the reduced dimension = the OTHER store's segment counts
+    if (cols && comm_) {
+        PROF(KernelProfiler::K_ALLREDUCE, comm_allreduce_f32(comm_, gh, (size_t) 2 * n_, st_));
+        f.cnt_override = global_col_nnz_.get();
+    }
+    SegStreamDev out_view;  // finalize from a dense buffer only needs the length
+    out_view.nseg = cols ? n_ : m_;
+    out_view.seg_cnt = f.cnt_override;
+    PROF(KernelProfiler::K_FINALIZE, launch_finalize(out_view, f, st_));
+    return MFX_OK;
+}
+
+int CcdSolver::rank_fused_scatter(uint32_t t) {
+    const uint32_t next = (t + 1) % k_;
+    // same invariant as rank_fused: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old).
+    // v-update: stream the ROW-major copy; columns are local (slice packB, accumulators), rows stream (packA)
+    PROF(KernelProfiler::K_SCAT_V, launch_scatter(SM_V, csr_.view, packB_.get(), packA_.get(), 0, st_));
+    FinalizeArgs fv;
+    fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next); fv.pack4 = packC_.get();
+    MFX_TRY(scatter_finalize(true, fv));
+    // u-update: stream the COLUMN-major copy; rows are local (slice packA), columns stream (packC)
+    PROF(KernelProfiler::K_SCAT_U, launch_scatter(SM_U, csc_.view, packA_.get(), packC_.get(), 0, st_));
+    FinalizeArgs fu;
+    fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
+    MFX_TRY(scatter_finalize(false, fu));
+    for (int it = 2; it <= p_.maxinneriter; ++it) {  // remaining inner iterations: read-only sweeps
+        MFX_TRY(sweep(csc_, Wt(t), Ht(t), true));
+        MFX_TRY(sweep(csr_, Ht(t), Wt(t), false));
+    }
+    if (p_.maxinneriter > 1) {
+        PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(t), Wt(next), packA_.get(), st_));
+        PROF(KernelProfiler::K_PACK, launch_pack2(n_, Ht(t), Ht(next), packB_.get(), st_));
+    }
+    pending_sub_ = (int32_t) t;
+    return MFX_OK;
+}
+
 int CcdSolver::rank_fused(uint32_t t) {
+    if (scatter_) return rank_fused_scatter(t);
     const uint32_t next = (t + 1) % k_;
     // invariant on entry: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old)
     PROF(KernelProfiler::K_FCSC, launch_flat(FM_FCSC, csc_.view, packA_.get(), packB_.get(), 0, st_));
@@ -606,8 +707,8 @@ int CcdSolver::rank_fused(uint32_t t) {
 int CcdSolver::flush_pending() {
     if (pending_sub_ < 0) return MFX_OK;
     const uint32_t t = (uint32_t) pending_sub_, next = (t + 1) % k_;
-    PROF(KernelProfiler::K_RESID, launch_flat(FM_RESID, csc_.view, Wt(t), Ht(t), 0, st_));
-    PROF(KernelProfiler::K_RESID, launch_flat(FM_RESID, csr_.view, Ht(t), Wt(t), 0, st_));
+    MFX_TRY(resid(csc_, Wt(t), Ht(t), 0));
+    MFX_TRY(resid(csr_, Ht(t), Wt(t), 0));
     PROF(KernelProfiler::K_PACK, launch_pack2(m_, nullptr, Wt(next), packA_.get(), st_));
     PROF(KernelProfiler::K_PACK, launch_pack2(n_, nullptr, Ht(next), packB_.get(), st_));
     pending_sub_ = -1;
@@ -618,6 +719,11 @@ int CcdSolver::sweep(SegStreamStore& s, const float* vec, float* out, bool is_co
     FinalizeArgs f;
     f.lambda = p_.lambda;
     f.out_vec = out;
+    if (scatter_) {  // sums over columns stream the row-major store (vec = u, by row), and vice versa
+        SegStreamStore& src = is_col_side ? csr_ : csc_;
+        PROF(KernelProfiler::K_SCAT_SWEEP, launch_scatter(SM_SWEEP, src.view, nullptr, vec, 0, st_));
+        return scatter_finalize(is_col_side, f);
+    }
     if (p_.kernel_variant == 0) {
         float* gh = is_col_side ? gh_cols_.get() : gh_rows_.get();
         PROF(KernelProfiler::K_SWEEP_WAVE, launch_sweep_wave(s.view, vec, gh, gh + s.view.nseg, st_));
@@ -636,6 +742,10 @@ int CcdSolver::sweep(SegStreamStore& s, const float* vec, float* out, bool is_co
 }
 
 int CcdSolver::resid(SegStreamStore& s, const float* gathered, const float* per_seg, int add) {
+    if (scatter_) {  // the store's own copy: local index = its gathered dimension (slice), segment id streams
+        PROF(KernelProfiler::K_SCAT_RESID, launch_scatter(SM_RESID, s.view, gathered, per_seg, add, st_));
+        return MFX_OK;
+    }
     if (p_.kernel_variant == 0)
         PROF(KernelProfiler::K_RESID_WAVE, launch_resid_wave(s.view, gathered, per_seg, add, st_));
     else

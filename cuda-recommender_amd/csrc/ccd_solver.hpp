@@ -41,6 +41,8 @@ private:
     DevBuf<float2> part_, carry_;
     DevBuf<uint32_t> rank_code_;
     DevBuf<uint16_t> idx16_;
+    DevBuf<uint32_t> segid_, wg_lo_;           // scatter layout
+    DevBuf<unsigned long long> wgacc_;
     // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
     std::vector<uint32_t> first_q_host_, panel_end_host_;
     DevBuf<uint32_t> first_q_dev_, panel_end_dev_;
@@ -64,7 +66,7 @@ public:
     void reset_totals();
     static const char* name(int id);
     enum { K_FCSC = 0, K_FCSR, K_SWEEP, K_RESID, K_FINALIZE, K_COMBINE, K_PACK, K_RMSE, K_ALLREDUCE,
-           K_SWEEP_WAVE, K_RESID_WAVE, K_COUNT };
+           K_SWEEP_WAVE, K_RESID_WAVE, K_SCAT_V, K_SCAT_U, K_SCAT_SWEEP, K_SCAT_RESID, K_SCAT_COMBINE, K_COUNT };
     double seconds[K_COUNT] = {};
     int64_t launches[K_COUNT] = {};
 
@@ -90,7 +92,7 @@ public:
     int set_profile(bool on);
     void layout_info(int side, int32_t out[4]) const {
         const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
-        out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
+        out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.scatter ? 2 : v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
     }
 
 private:
@@ -102,6 +104,11 @@ private:
     int flush_pending();
     int sweep(SegStreamStore& s, const float* vec, float* out, bool is_col_side);
     int resid(SegStreamStore& s, const float* gathered, const float* per_seg, int add);
+    // scatter mode (hyper-sparse: both stores in the scatter layout, roles swapped -- see ccd_scatter.hip):
+    // sums over COLUMNS come from the row-major store csr_, sums over ROWS from csc_
+    bool scatter_ = false;
+    int scatter_finalize(bool cols, const FinalizeArgs& base);  // slabs -> dense (g,h) -> [all-reduce] -> finalize
+    int rank_fused_scatter(uint32_t t);
     int finalize_cols(const FinalizeArgs& base);  // CSC side: all-reduce across shards if sharded
     int test_rmse(double* rmse_out);
     float* Wt(uint32_t t) { return W_.get() + (size_t) t * m_; }
@@ -138,6 +145,7 @@ private:
     hipGraphExec_t graph_exec_ = nullptr;
     bool graph_failed_ = false;
     int enqueue_outer_iteration(int64_t oiter);
+    int build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace space, bool scatter);
 };
 
 }  // namespace mfx

@@ -147,6 +147,9 @@ struct FlatLayoutOptions {
     bool emit_idx16 = false;
     bool emit_val = false;
     bool compact_perm = false;    // see FlatLayoutHost::perm_is_runs
+    // scatter layout (ccd_scatter.hip): LDS panels + an explicit per-element segment id, no flags / ranks /
+    // partials; built by the device pipeline only
+    bool scatter = false;
     const float* val = nullptr;   // input-order values for emit_val; nullptr = zeros
 };
 

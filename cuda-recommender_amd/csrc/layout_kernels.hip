@@ -225,14 +225,14 @@ __global__ __launch_bounds__(kLB) void k_place(LayoutBuildIn in, uint64_t padded
                                                const uint32_t* __restrict__ first_q, const uint32_t* __restrict__ cnt,
                                                const uint32_t* __restrict__ flags32, const uint32_t* __restrict__ hpre,
                                                const uint32_t* __restrict__ v_of_rank, void* __restrict__ idx_out,
-                                               float* __restrict__ val_out) {
+                                               float* __restrict__ val_out, uint32_t* __restrict__ seg_out) {
     const uint64_t d0 = ((uint64_t) blockIdx.x * kLB + threadIdx.x) * 4;
     if (d0 >= padded) return;
     const uint32_t w = (uint32_t) (d0 >> 5), sh = (uint32_t) (d0 & 31);
     const uint32_t fl = flags32[w];
     uint32_t r1 = hpre[w] + (uint32_t) __popc(fl & ((1u << sh) - 1u));  // heads before d0
-    uint32_t cur = kNone, pv = 0, cn = 0, fq = 0, pbase = 0;
-    uint32_t oi[4];
+    uint32_t cur = kNone, pv = 0, cn = 0, fq = 0, pbase = 0, seg = 0;
+    uint32_t oi[4], os[4];
     float ov[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -243,15 +243,18 @@ __global__ __launch_bounds__(kLB) void k_place(LayoutBuildIn in, uint64_t padded
             const uint32_t v = v_of_rank[rank];
             pv = ptr_v[v]; cn = cnt[v]; fq = first_q[v];
             pbase = in.local_idx ? (v / in.nseg) * in.panel_rows : 0u;
+            seg = v % in.nseg;
         }
         const uint32_t off = (uint32_t) d0 + e - pv;
         if (off < cn) {
             const uint32_t q = fq + off;
             oi[e] = in.idx[q] - pbase;
             ov[e] = in.val ? in.val[q] : 0.f;
+            os[e] = seg;
         } else {  // padding folded into the panel's last virtual segment
             oi[e] = in.pad_index;
             ov[e] = 0.f;
+            os[e] = 0u;
         }
     }
     if constexpr (IDX16) {
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(kLB) void k_place(LayoutBuildIn in, uint64_t padded
         *reinterpret_cast<uint4*>(static_cast<uint32_t*>(idx_out) + d0) = make_uint4(oi[0], oi[1], oi[2], oi[3]);
     }
     *reinterpret_cast<float4*>(val_out + d0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    if (seg_out) *reinterpret_cast<uint4*>(seg_out + d0) = make_uint4(os[0], os[1], os[2], os[3]);
 }
 
 __global__ __launch_bounds__(kLB) void k_max_wg_ranks(const uint32_t* __restrict__ hpre, size_t nwords, size_t chunk_words,
@@ -382,10 +386,11 @@ int lk_ranks(const uint32_t* ptr_v, size_t nv, uint32_t nseg, uint32_t span_len,
 }
 
 int lk_place(const LayoutBuildIn& in, uint64_t padded, const uint32_t* ptr_v, const uint32_t* first_q, const uint32_t* cnt,
-             const uint32_t* flags32, const uint32_t* hpre, const uint32_t* v_of_rank, void* idx_out, float* val_out, hipStream_t st) {
+             const uint32_t* flags32, const uint32_t* hpre, const uint32_t* v_of_rank, void* idx_out, float* val_out,
+             uint32_t* seg_out, hipStream_t st) {
     const dim3 grid(grid_for(padded, kLB * 4)), block(kLB);
-    if (in.idx16) hipLaunchKernelGGL(k_place<true>, grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out);
-    else hipLaunchKernelGGL(k_place<false>, grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out);
+    if (in.idx16) hipLaunchKernelGGL(k_place<true>, grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out, seg_out);
+    else hipLaunchKernelGGL(k_place<false>, grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out, seg_out);
     LK_LAUNCH_CHECK();
     return MFX_OK;
 }

@@ -68,10 +68,11 @@ int lk_heads(const uint32_t* ptr_v, size_t nv, uint32_t* flags32, hipStream_t st
 int lk_ranks(const uint32_t* ptr_v, size_t nv, uint32_t nseg, uint32_t span_len, const uint32_t* flags32,
              const uint32_t* hpre, uint32_t* rank_code, uint32_t* seg_of_rank, uint32_t* v_of_rank, hipStream_t st);
 
-// stored arrays: idx_out is uint16[padded] (in.idx16) or uint32[padded]; val_out float[padded]
+// stored arrays: idx_out is uint16[padded] (in.idx16) or uint32[padded]; val_out float[padded];
+// seg_out (may be nullptr) uint32[padded]: the segment of every stored element, 0 for padding
 int lk_place(const LayoutBuildIn& in, uint64_t padded, const uint32_t* ptr_v, const uint32_t* first_q, const uint32_t* cnt,
              const uint32_t* flags32, const uint32_t* hpre, const uint32_t* v_of_rank, void* idx_out, float* val_out,
-             hipStream_t st);
+             uint32_t* seg_out, hipStream_t st);
 
 // max over workgroup chunks of the ranks a chunk touches (incl. the one open at its start) -> *out (device word, zeroed by the caller)
 int lk_max_wg_ranks(const uint32_t* hpre, size_t nwords, size_t chunk_words, uint32_t* out, hipStream_t st);

@@ -4,8 +4,12 @@
 // log lines in the same order, the same post-run checks -- so that scripts written against the
 // reference (scripts/times.sh and friends) keep working -- with the GPU leg served by this repository's
 // HIP implementation behind kernel_wrapper_{ccdpp,als}_NV.  Two steps the reference only stubs out are
-// real here: -save <file> (model dump) and -predict (file-based scoring).  The reference's -OMP leg,
-// its CPU solver, is not part of the product; the CPU restatement lives under oracle/ as a test oracle.
+// real here: -save <file> (model dump) and -predict (file-based scoring).  The reference's -OMP leg is
+// its CPU solver, which is not part of the product (the CPU restatement lives under oracle/ as a test
+// oracle): here -OMP runs the SECOND, independent implementation this library has -- the as-written
+// schedule (one launch per reference kernel for CCD++; for ALS the reference's own operation order, which
+// reproduces src/ALS.cpp bit for bit) -- from the same initial factors, so that the driver's closing
+// golden_compare cross-checks two implementations exactly as the reference's -CUDA -OMP run does.
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -102,11 +106,21 @@ int main(int argc, char* argv[]) {
     }
     if (prm.enable_omp) {
         rule();
-        puts("[info] -OMP: the CPU solver is not built into mfx_train (it exists as the test oracle under oracle/).");
+        puts("[INFO] Computing with OMP...");  // log line of src/main.cpp:122; the leg itself: see the header comment
+        puts("[info] -OMP leg = as-written schedule on the GPU (reference operation order; no CPU solver in this build)");
+        parameter second = prm;
+        second.schedule = 0;
+        second.kernel_variant = 1;
+        const Stopwatch sw;
+        solve_on_gpu(R, T, untouched, second, als);
+        printf("[info] OMP Training time: %lf s.\n", sw.seconds());
+        rule();
+        calculate_rmse_directly(untouched.W, untouched.H, T, prm.k, als);
     }
 
-    // The reference compares against the factors of its -OMP leg; without one they are still the
-    // initial values, and -- exactly like the reference run with -CUDA only -- the check reports that.
+    // The reference compares the -CUDA factors with the -OMP leg's; a leg that did not run leaves its
+    // factors at the initial values, and -- exactly like the reference run with one flag only -- the check
+    // then reports a mismatch.
     std::cout << "[info] validate the results." << std::endl;
     const long w_outer = als ? R.rows : (long) prm.k, w_inner = als ? (long) prm.k : R.rows;
     const long h_outer = als ? R.cols : (long) prm.k, h_inner = als ? (long) prm.k : R.cols;

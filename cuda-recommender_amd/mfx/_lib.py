@@ -90,8 +90,9 @@ SIGNATURES = {
     "mfx_test_rmse": (C.c_int, [C.POINTER(mfx_coo), f32p, f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int, f64p,
                                 C.c_int]),
     "mfx_als_gramian": (C.c_int, [C.c_int64, u32p, C.c_int64, f32p, C.c_int64, f32p, C.c_int]),
+    "mfx_als_inverse": (C.c_int, [C.c_int64, f32p, f32p, C.c_int]),
     "mfx_als_half": (C.c_int, [C.c_int64, C.c_int64, u32p, u32p, f32p, C.c_int64, f32p, f32p, C.c_int64,
-                               C.c_float, C.c_int]),
+                               C.c_float, C.c_int, C.c_int]),
     "mfx_comm_unique_id": (C.c_int, [C.c_void_p]),
     "mfx_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mfx_comm_create_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),

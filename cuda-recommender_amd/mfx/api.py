@@ -389,7 +389,7 @@ class CcdSolver:
             v = (C.c_int32 * 4)()
             L.check(L.lib().mfx_ccd_layout_info(self.handle, side, v))
             out[name] = {"panels": int(v[0]), "panel_rows": int(v[1]),
-                         "kind": "lds" if v[2] else ("cache" if v[1] else "plain"),
+                         "kind": "scatter" if v[2] == 2 else "lds" if v[2] else ("cache" if v[1] else "plain"),
                          "tiles_per_span": int(v[3])}  # kind "tile": panel_rows = slice entries, tiles_per_span = segments per block
         return out
 
@@ -514,12 +514,21 @@ def als_gramian(idx, X, k: int, device: int = 0) -> np.ndarray:
     return A
 
 
-def als_half(ptr, idx, val, X, k: int, lam: float, device: int = 0) -> np.ndarray:
+def als_half(ptr, idx, val, X, k: int, lam: float, device: int = 0, variant: int = 1) -> np.ndarray:
+    """variant 1: MFMA Gramian + Cholesky solve (the product path); 0: as written, bit-identical to src/ALS.cpp."""
     nseg = ptr.shape[0] - 1
     Y = np.empty((nseg, k), np.float32)
     L.check(L.lib().mfx_als_half(nseg, idx.shape[0], _u32(ptr), _u32(idx), _f32(val), X.shape[0], _f32(X), _f32(Y),
-                                 k, lam, device))
+                                 k, lam, variant, device))
     return Y
+
+
+def als_inverse(A, device: int = 0) -> np.ndarray:
+    """inverseMatrix_CholeskyMethod (src/ALS.cpp:41-64) on one matrix, the reference's operation order."""
+    A = np.ascontiguousarray(A, np.float32)
+    out = np.empty_like(A)
+    L.check(L.lib().mfx_als_inverse(A.shape[0], _f32(A), _f32(out), device))
+    return out
 
 
 def partition_rows(R: RatingData, nshards: int) -> np.ndarray:

@@ -78,8 +78,12 @@ typedef struct mfx_params {
     int32_t device;            /* HIP device ordinal (reference hard-codes 0)            */
     int32_t schedule;          /* CCD++ kernel schedule: 0 = as written (separate add-back,
                                   sweeps, subtract launches, one per reference kernel),
-                                  1 = fused passes (default; same arithmetic, fewer bytes) */
-    int32_t kernel_variant;    /* schedule 0 only: 0 = wave-per-segment kernels, 1 = flat-stream */
+                                  1 = fused passes (default; same arithmetic, fewer bytes).
+                                  ALS: 0 = as written (explicit Cholesky inverse in the reference's operation
+                                  order, bit-identical to src/ALS.cpp), 1 = MFMA Gramian + Cholesky solve */
+    int32_t kernel_variant;    /* 0 = wave-per-segment kernels (schedule 0 only), 1 = flat-stream kernels (default),
+                                  2 = force the scatter layout (csrc/ccd_scatter.hip), which hyper-sparse shapes
+                                  get on their own: < 8 entries per (LDS panel, row / column) pair */
     int32_t profile;           /* 1: bracket every launch with HIP events (mfx_*_kernel_times) */
     int32_t tiles_per_span;    /* flat-stream span length / 256; 0 = choose from nnz */
     int32_t panel_rows;        /* panels of the gathered index space. 0 = choose (LDS panels, 64 KB of LDS per
@@ -163,8 +167,8 @@ int mfx_ccd_kernel_times(mfx_ccd_t s, int cap, const char** names, double* secon
 /* Turns the per-launch event bracketing (mfx_params.profile) on or off between iterate calls. */
 int mfx_ccd_set_profile(mfx_ccd_t s, int on);
 /* Layout the solver chose for one residual copy (side 0 = CSC / column segments, 1 = CSR / row
- * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 1 LDS
- * panels / 0 cache panels or plain, out[3] = tiles per span (tile order: segments per block).  For logs,
+ * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 2 scatter
+ * layout / 1 LDS panels / 0 cache panels or plain, out[3] = tiles per span (tile order: segments per block).  For logs,
  * benchmarks and tests. */
 int mfx_ccd_layout_info(mfx_ccd_t s, int side, int32_t out[4]);
 int mfx_ccd_destroy(mfx_ccd_t s);
@@ -217,11 +221,19 @@ int mfx_test_rmse(const mfx_coo* T, const float* W, const float* H, int64_t rows
 /* Mt_byM_multiply_k (cuda_src/ALS_CUDA.cu:65-79): A[k][k] = sum over idx of x x^T. */
 int mfx_als_gramian(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const float* X, int64_t k,
                     float* A, int device);
+/* inverseMatrix_CholeskyMethod_k (cuda_src/ALS_CUDA.cu:41-62) == choldc1 / choldcsl /
+ * inverseMatrix_CholeskyMethod (src/ALS.cpp:6-64) on one k x k matrix, in the reference's operation order
+ * (bit-identical to the CPU reference): Ainv = A^-1 via Cholesky, mirrored. */
+int mfx_als_inverse(int64_t k, const float* A, float* Ainv, int device);
 /* One ALS half-sweep, updateW_overH_kernel / updateH_overW_kernel
- * (cuda_src/ALS_CUDA.cu:81-181): for every segment solve (X^T X + lambda I) y = X^T r. */
+ * (cuda_src/ALS_CUDA.cu:81-181): for every segment solve (X^T X + lambda I) y = X^T r.
+ * variant 1 (default path): MFMA Gramian, Cholesky factorisation and two triangular solves; variant 0:
+ * "as written" -- Gramian, explicit inverse and products in the reference's own operation order
+ * (src/ALS.cpp:66-79, 6-64, 129-142), bit-identical to the CPU reference; the parity mode, also selected by
+ * mfx_params.schedule = 0 in mfx_als_run / mfx_als_create. */
 int mfx_als_half(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx,
                  const float* val, int64_t nrows_x, const float* X, float* Y, int64_t k,
-                 float lambda, int device);
+                 float lambda, int variant, int device);
 
 /* ------------------------------------------------------------------------------------
  * Communicator over RCCL (the reference has no distributed code).

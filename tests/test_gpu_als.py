@@ -8,7 +8,7 @@ these (deliberately ill-conditioned, tiny) systems and test RMSE to 1e-4.
 import numpy as np
 import pytest
 
-from conftest import CASES, load_golden
+from conftest import CASES, bits, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -71,13 +71,52 @@ def test_als_matches_reference_golden(mfx, name):
     reports = mfx.kernel_wrapper_als_NV(d, mfx.test_data_of(d), W, H, p)
     assert mfx.kernel_wrapper_als_NV.last_status == 0
     rmse = np.array([r.rmse for r in reports])
-    # 1e-4 is the north-star bar.  The 60x40 fixture is underdetermined (most rows have fewer ratings
-    # than k, lambda = 0.05, ALS RMSE ~1.7-2.0 and not converging): on the CPU alone, merely
+    # This is the PRODUCT path (MFMA Gramian = fused multiply-adds, Cholesky solve instead of the explicit
+    # inverse).  1e-4 is the north-star bar.  The 60x40 fixture is underdetermined (most rows have fewer
+    # ratings than k, lambda = 0.05, ALS RMSE ~1.7-2.0 and not converging): on the CPU alone, merely
     # FMA-contracting the reference's sums moves its RMSE by 1.3e-4 and solving instead of inverting
-    # by 1.7e-4 (profiles/r01_als_sensitivity.txt), so that case is compared at 3e-4.
+    # by 1.7e-4 (profiles/r01_als_sensitivity.txt), so that case is compared at 3e-4 here -- and BIT FOR BIT
+    # in the as-written mode (test_als_as_written_matches_reference_golden_bit_exact).
     tol = 3e-4 if name == "tiny" else 1e-4
     assert np.all(np.abs(rmse - g["als__rmse"]) < tol), (rmse, g["als__rmse"])
     assert relerr(W, g["als__W"]) < 5e-3 and relerr(H, g["als__H"]) < 5e-3
+
+
+# ---- ALS "as written" (mfx_params.schedule = 0 / variant 0): the reference's operation order, BIT FOR BIT
+@pytest.mark.parametrize("name", CASES)
+def test_inverse_golden_bit_exact(mfx, name):
+    """inverseMatrix_CholeskyMethod on the golden Gramian (+ lambda): equal to the reference's step_inv bit for bit."""
+    g, d = load_golden(name)
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    A = np.array(g["step_gram"], np.float32, copy=True)
+    A[np.arange(k), np.arange(k)] = A[np.arange(k), np.arange(k)] + np.float32(lam)
+    assert np.array_equal(bits(mfx.als_inverse(A)), bits(g["step_inv"]))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_als_as_written_matches_reference_golden_bit_exact(mfx, name):
+    """kernel_wrapper_als_NV with schedule 0 vs the reference's own ALS_OMP output: W, H bit for bit, the
+    printed RMSE to its 6 decimals -- on every fixture, the underdetermined 60x40 one included."""
+    g, d = load_golden(name)
+    k, lam, t = int(g["k"][0]), float(g["lam"][0]), int(g["als__maxiter"][0])
+    p = mfx.parameter(); p.k, p.lambda_, p.maxiter, p.schedule = k, lam, t, 0
+    W = np.zeros((d.rows, k), np.float32)
+    H = np.array(g["als__H0"], np.float32, copy=True)
+    reports = mfx.kernel_wrapper_als_NV(d, mfx.test_data_of(d), W, H, p)
+    assert mfx.kernel_wrapper_als_NV.last_status == 0
+    assert np.array_equal(bits(W), bits(g["als__W"])) and np.array_equal(bits(H), bits(g["als__H"]))
+    assert np.allclose([r.rmse for r in reports], g["als__rmse"], rtol=0, atol=5.1e-7)
+
+
+@pytest.mark.parametrize("k", [3, 40, 64, 100, 128])
+def test_als_as_written_half_vs_oracle_bit_exact(mfx, orc, k):
+    d = mfx.dataset.synth_ratings(500, 90, 9000, seed=7 + k, skew=1.0, test_frac=0.01, empty_row_frac=0.03)
+    H0 = mfx.initial_col(d.cols, k)
+    W1 = mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, k, 0.05, variant=0)
+    ref = orc.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, k, 0.05, 2)
+    assert np.array_equal(bits(W1), bits(ref))
+    # and the product path against the same: tolerance only
+    assert relerr(mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, k, 0.05), ref) < 5e-3
 
 
 @pytest.mark.parametrize("k", [10, 36, 40, 60, 64, 128])

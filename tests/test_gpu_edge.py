@@ -108,20 +108,57 @@ def test_many_one_entry_segments_overflow_the_lds_rank_window(mfx, orc):
 
 
 def test_hyper_sparse_shard_layouts(mfx, orc):
-    """600 k x 40 k with 4.2 M ratings: LDS-sized panels would leave ~1 entry per (panel, segment) pair,
-    so the column side must come out as 2 MB cache panels (global indices, L2 gather) and the row side
-    -- whose gathered vector is below 2 MB -- as the plain layout.  Results as the oracle's, with the layout
-    built on the device and on the host."""
+    """600 k x 40 k with 4.2 M ratings: LDS-sized panels would leave ~1 entry per (panel, segment) pair.
+    By default such a shape takes the SCATTER layout on both sides (ccd_scatter.hip); with the host builder
+    (layout_build = 1) the round-1 layouts remain: 2 MB cache panels on the column side (global indices, L2
+    gather), plain on the row side -- whose gathered vector is below 2 MB.  Results as the oracle's either way,
+    fused and as-written, T = 1 and T = 2, and bitwise reproducible."""
     d = mfx.dataset.synth_ratings(600000, 40000, 4200000, seed=21, skew=0.3, test_frac=0.002)
     s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2))
+    info = s.layout_info()
+    s.close()
+    assert info["csc"]["kind"] == "scatter" and info["csr"]["kind"] == "scatter" and info["csc"]["panel_rows"] == 6144, info
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2, layout_build=1))
     info = s.layout_info()
     s.close()
     assert info["csc"]["kind"] == "cache" and info["csc"]["panels"] == 3 and info["csc"]["panel_rows"] == 262144, info
     assert info["csr"]["kind"] == "plain", info
     a = _check(mfx, orc, d, 2, t=2)
-    b = _check(mfx, orc, d, 2, t=2, layout_build=1)
-    assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b))
+    b = _check(mfx, orc, d, 2, t=2)
+    assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b))  # 64-bit fixed-point accumulation: order-free
+    _check(mfx, orc, d, 2, t=2, layout_build=1)
     _check(mfx, orc, d, 2, t=2, T=2)
+    _check(mfx, orc, d, 2, t=2, schedule=0, kernel_variant=2)
+    c = _check(mfx, orc, d, 2, t=2, panel_rows=-262144)   # cache panels forced, device-built
+    assert np.array_equal(bits(c[2]), bits(a[2])) and np.array_equal(bits(c[3]), bits(a[3]))  # residual copies: same bits whichever kernel
+
+
+@pytest.mark.parametrize("kw", [{}, {"schedule": 0}, {"maxinneriter": 3}, {"panel_rows": 40}, {"panel_rows": 7, "tiles_per_span": 2}])
+@pytest.mark.parametrize("name", ["tiny", "small", "edge"])
+def test_scatter_layout_on_golden(mfx, name, kw):
+    """kernel_variant = 2 forces the scatter layout on the reference-generated fixtures (empty rows / columns, a
+    full row, a full column, 1-entry segments; several panels with panel_rows = 7 / 40): factors, RMSE and
+    both residual copies against the golden output."""
+    from conftest import load_golden
+    g, d = load_golden(name)
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    T = kw.get("maxinneriter", 1)
+    tag = "ccd_T3" if T == 3 else "ccd_T1"
+    t = int(g[tag + "__maxiter"][0])
+    p = _p(mfx, k, t, T, kernel_variant=2, **{a: b for a, b in kw.items() if a != "maxinneriter"})
+    p.lambda_ = lam
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), p)
+    assert d.nnz == 0 or s.layout_info()["csc"]["kind"] == "scatter"
+    s.set_factors(np.array(g[tag + "__W0"], np.float32, copy=True))
+    rep = s.iterate(t)
+    W, H = s.get_factors()
+    csc, csr = s.get_residual(d.nnz)
+    s.close()
+    scale = float(max(np.abs(g[tag + "__W"]).max(), np.abs(g[tag + "__H"]).max()))
+    assert np.abs(W - g[tag + "__W"]).max() < 2e-3 * scale and np.abs(H - g[tag + "__H"]).max() < 2e-3 * scale
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - g[tag + "__rmse"]) < 1e-4)
+    if tag == "ccd_T1":
+        assert np.max(np.abs(csc - g["ccd_T1__csc_val_final"])) < 2e-4 and np.max(np.abs(csr - g["ccd_T1__csr_val_final"])) < 2e-4
 
 
 def test_bad_arguments_are_errors(mfx):
