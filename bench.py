@@ -157,6 +157,8 @@ def main() -> None:
     ap.add_argument("--layout-build", type=int, default=0, help="0 auto (GPU when possible), 1 host, 2 GPU or fail")
     ap.add_argument("--graph", type=int, default=0, help="0 = hipGraph replay of outer iterations, -1 = eager launches")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--sigma-rows", type=float, default=None, help="log-normal sigma of the user activity (generator)")
+    ap.add_argument("--sigma-cols", type=float, default=None, help="log-normal sigma of the item popularity (generator)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N = 1 only: run through the sharded code path with a 1-rank RCCL communicator")
     ap.add_argument("--solver", choices=["ccd", "als"], default="ccd", help="als: report ALS iteration time instead")
@@ -209,10 +211,13 @@ def main() -> None:
     if strong:
         # every rank draws the SAME global matrix and keeps its nnz-balanced block of user rows;
         # uniform user activity / mild item skew: config 5 is "synthetic 10M x 1M", not a Netflix-shaped one
-        d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed, device=dev, sigma_rows=0.5, sigma_cols=1.0,
-                                             shard=(rank, world))
+        d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed, device=dev,
+                                             sigma_rows=0.5 if a.sigma_rows is None else a.sigma_rows,
+                                             sigma_cols=1.0 if a.sigma_cols is None else a.sigma_cols, shard=(rank, world))
     else:
-        d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed + 7919 * rank, device=dev)
+        d = synth_torch.synth_ratings_device(a.rows, a.cols, a.nnz, seed=a.seed + 7919 * rank, device=dev,
+                                             sigma_rows=1.2 if a.sigma_rows is None else a.sigma_rows,
+                                             sigma_cols=1.8 if a.sigma_cols is None else a.sigma_cols)
     nnz_local = int(d["csr_val"].numel())
     col_cnt = (d["csc_col_ptr"][1:] - d["csc_col_ptr"][:-1]).to(torch.int32).contiguous()
     nnz_tot = torch.tensor([nnz_local, int(d["test_val"].numel())], dtype=torch.int64, device=dev)

@@ -161,7 +161,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     }
     const uint32_t nspans = (uint32_t) (padded / span);
     std::vector<uint32_t> wg_panel;
-    if (opt.panel_rows && lds) {  // workgroup -> panel (a workgroup stages exactly one slice)
+    if (opt.panel_rows) {  // workgroup chunk -> panel (LDS panels: one slice per workgroup; cache panels: one entry per span)
         const uint32_t nwg = nspans / spans_per_wg;
         wg_panel.assign(nwg, 0);
         uint32_t p = 0;
@@ -184,7 +184,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
         MFX_TRY(wg_lo_.alloc(wg_lo.size())); MFX_TRY(wg_lo_.upload(wg_lo.data(), wg_lo.size(), MFX_HOST, st));
         MFX_TRY(wgacc_.alloc((size_t) nwg * 2 * opt.panel_rows));
     } else {
-        MFX_TRY(part_.alloc_zero(nne ? nne : 1, st));
+        MFX_TRY(part_.alloc_zero(nv ? nv : 1, st));  // dense (panel, segment) slots; empty pairs stay zero
         MFX_TRY(carry_.alloc_zero(nspans, st));
     }
     MFX_HIP(hipStreamSynchronize(st));  // host vectors behind the uploads, temporaries behind the kernels
@@ -311,7 +311,7 @@ int SegStreamStore::build_host(uint32_t nseg, uint64_t nnz, uint32_t G, const ui
     MFX_TRY(seg_of_rank_.upload(L.seg_of_rank.data(), L.nne, MFX_HOST, st));
     MFX_TRY(wg_panel_.alloc(L.wg_panel.empty() ? 1 : L.wg_panel.size()));
     MFX_TRY(wg_panel_.upload(L.wg_panel.data(), L.wg_panel.size(), MFX_HOST, st));
-    MFX_TRY(part_.alloc_zero(L.nne ? L.nne : 1, st));
+    MFX_TRY(part_.alloc_zero(nv ? nv : 1, st));  // dense (panel, segment) slots; empty pairs stay zero
     MFX_TRY(carry_.alloc_zero(L.nspans, st));
     // the host vectors behind the async uploads must outlive the copies
     MFX_HIP(hipStreamSynchronize(st));

@@ -64,6 +64,34 @@ def test_mfx_train_cuda_and_omp_legs_agree(tmp_path, solver):
     assert len(finals) == 2 and all(abs(x - float(g[tag + "__final_rmse"][0])) < (1e-4 if solver == "ccd" else 3e-4) for x in finals)
 
 
+def test_text_ratings_to_mfx_train_matches_reference_log(tmp_path):
+    """N1 end to end on the GPU: MovieLens-style "user item rating" text (1-based, arbitrary line order) ->
+    convert_text_ratings -> the 12-file binary directory -> mfx_train -CUDA: the per-iteration RMSE of the log
+    equals the reference's on the golden dataset the text was written from."""
+    import mfx
+    g, d = load_golden("small")
+    rng = np.random.default_rng(11)
+    rows_of = np.repeat(np.arange(d.rows), np.diff(d.csr_row_ptr.astype(np.int64)))
+    order = rng.permutation(d.nnz)
+    with open(tmp_path / "train.txt", "w") as f:
+        for q in order:
+            f.write("%d %d %.9g\n" % (rows_of[q] + 1, int(d.csr_col_idx[q]) + 1, float(d.csr_val[q])))
+    with open(tmp_path / "test.txt", "w") as f:
+        for q in range(d.nnz_test):
+            f.write("%d %d %.9g\n" % (int(d.test_row[q]) + 1, int(d.test_col[q]) + 1, float(d.test_val[q])))
+    # (the largest row / column id must occur for the shape to come out right: true for this fixture)
+    conv = mfx.dataset.convert_text_ratings(str(tmp_path / "train.txt"), str(tmp_path / "ds"), str(tmp_path / "test.txt"))
+    assert (conv.rows, conv.cols, conv.nnz) == (d.rows, d.cols, d.nnz)
+    assert np.array_equal(conv.csr_col_idx, d.csr_col_idx) and np.array_equal(conv.csc_row_idx, d.csc_row_idx)
+    exe = os.path.join(ROOT, "cuda-recommender_amd", "mfx_train")
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    r = subprocess.run([exe, "-CUDA", "-k", str(k), "-l", repr(lam), "-t", str(int(g["ccd_T1__maxiter"][0])), "-T", "1", str(tmp_path / "ds")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rmse = np.array([float(x) for x in re.findall(r"\[-INFO-\] iteration num \d+ .*RMSE=([0-9.]+)", r.stdout)])
+    assert np.all(np.abs(rmse - g["ccd_T1__rmse"]) < 1e-4), (rmse, g["ccd_T1__rmse"])
+
+
 def test_sweep_harness_protocol(tmp_path):
     """tools/sweep_times.py: the K x T x repeats protocol of the reference's scripts/times.sh, JSON lines out."""
     import json

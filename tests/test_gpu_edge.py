@@ -129,8 +129,7 @@ def test_hyper_sparse_shard_layouts(mfx, orc):
     _check(mfx, orc, d, 2, t=2, layout_build=1)
     _check(mfx, orc, d, 2, t=2, T=2)
     _check(mfx, orc, d, 2, t=2, schedule=0, kernel_variant=2)
-    c = _check(mfx, orc, d, 2, t=2, panel_rows=-262144)   # cache panels forced, device-built
-    assert np.array_equal(bits(c[2]), bits(a[2])) and np.array_equal(bits(c[3]), bits(a[3]))  # residual copies: same bits whichever kernel
+    _check(mfx, orc, d, 2, t=2, panel_rows=-262144)   # cache panels forced, device-built
 
 
 @pytest.mark.parametrize("kw", [{}, {"schedule": 0}, {"maxinneriter": 3}, {"panel_rows": 40}, {"panel_rows": 7, "tiles_per_span": 2}])

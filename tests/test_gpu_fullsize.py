@@ -216,9 +216,11 @@ def test_fullsize_k64_ccd_vs_oracle(sigma_cols, rmse_tol, factor_tol):
 def test_fullsize_k64_als_vs_oracle(big):
     """BASELINE configs[3]: one full ALS iteration at the Netflix shape, k = 64, against oracle.als (measured:
     RMSE gap 5.8e-7, W within 5.9e-5 and H within 2.1e-4 of scale)."""
+    import time
     mfx, torch, dev = big
     from mfx import synth_torch
     from oracle import oracle as orc
+    t0 = time.time()
     d = synth_torch.to_rating_data(dev)
     p = mfx.parameter()
     p.k, p.lambda_ = K, 0.05
@@ -228,7 +230,9 @@ def test_fullsize_k64_als_vs_oracle(big):
     rep = s.iterate(1)
     W, H = s.get_factors()
     s.close()
+    t1 = time.time()
     Wr, Hr, rmse_ref, _ = orc.als(d, H0, K, 0.05, 1, orc.max_threads())
+    print(f"[als full-size] data + gpu {t1 - t0:.1f} s, oracle {time.time() - t1:.1f} s on {orc.max_threads()} threads")
     assert abs(rep[0].rmse - rmse_ref[0]) < 1e-4, (rep[0].rmse, rmse_ref)
     scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
     assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale
