@@ -69,6 +69,12 @@ __device__ __forceinline__ f32x2 add2_rn(f32x2 a, f32x2 b) {
     return a + b;
 }
 
+// Blocked MFMA Cholesky for k > 32 (chol_blocked); false = the round-1 row-by-row forms, kept for A/B runs.
+#ifndef MFX_ALS_BLOCKED
+#define MFX_ALS_BLOCKED 1
+#endif
+constexpr bool kBlockedCholesky = MFX_ALS_BLOCKED != 0;
+
 struct AlsArgs {
     const AlsItem* items;
     const AlsReduce* reduces;
@@ -125,6 +131,103 @@ __device__ __forceinline__ void stage_tiles32(f32x16 (&acc)[Tiles<NT>::kCount], 
     }
 }
 
+
+// ---- Blocked Cholesky on the matrix cores, for KP = 32 * NT with NT >= 2 -----------------------------------
+// The packed lower-triangular LDS image is factored block column by block column (32 x 32 blocks):
+//   update   T_IJ = A_IJ - sum_{K<J} L_IK L_JK^T   v_mfma_f32_32x32x2_f32: lane (r, h) feeds row r of both blocks,
+//            four consecutive columns per ds_read_b128 (columns 8t+4h+e in MFMA step 4t+e: the two halves of the
+//            wave cover the K dimension between them)
+//   panel    columns of block column J, one at a time, for 64 rows per pass: every lane keeps its row of the
+//            panel in registers (the k <= 64 scheme: pivot row by LDS broadcast, packed fp32 math) and computes
+//            L[row][i] = (T[row][i] - sum_{q<i} L[i][q] L[row][q]) / p_i.  First pass: lanes 0..31 hold the
+//            diagonal block (they produce the pivots), lanes 32..63 the block below it -- its triangular solve
+//            is the very same update; further passes take two more blocks each, with the pivots read back.
+// Against the row-by-row form this takes the O(k^3) part off the VALU / LDS path (which bounded k > 64: every
+// product needed two LDS rows, 200 ms per iteration at k = 128).  Rows / columns k .. KP-1 of the image are an
+// identity block (set by the caller).
+template <bool DIAG>
+__device__ __forceinline__ void chol_panel_pass(float* __restrict__ L, int J, int blk_lo, int blk_hi, bool& spd_ok) {
+    const int lane = (int) (threadIdx.x & 63), r31 = lane & 31, h = lane >> 5;
+    const bool stores = h == 0 || blk_hi >= 0;                    // lanes 32..63 without a block of their own shadow blk_lo
+    const int row = ((h && blk_hi >= 0) ? blk_hi : blk_lo) * 32 + r31;
+    float* blk = L + roff(row) + J * 32;
+    f32x2 r2[16];
+#pragma unroll
+    for (int q = 0; q < 32; q += 4) {  // (diagonal block: reads past the diagonal stay inside the image, never used)
+        const f32x4 x = *reinterpret_cast<const f32x4*>(blk + q);
+        r2[q / 2] = x.lo;
+        r2[q / 2 + 1] = x.hi;
+    }
+    auto rl = [](float x, int src_lane) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+    };
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float* pivrow = L + roff(J * 32 + i) + J * 32;  // row i of L_JJ: the same address in every lane
+        f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q + 4 <= i; q += 4) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(pivrow + q);
+            s01 = add2_rn(s01, mul2_rn(x.lo, r2[q / 2]));
+            s23 = add2_rn(s23, mul2_rn(x.hi, r2[q / 2 + 1]));
+        }
+#pragma unroll
+        for (int q = i & ~3; q < i; ++q) s01.x = add_rn(s01.x, mul_rn(pivrow[q], r2[q / 2][q & 1]));
+        const float sum = sub_rn(r2[i / 2][i & 1], add_rn(add_rn(s01.x, s01.y), add_rn(s23.x, s23.y)));
+        float lji;
+        if constexpr (DIAG) {
+            const float piv = rl(sum, i);  // lane i < 32 owns the diagonal entry
+            spd_ok = spd_ok && piv > 0.f;
+            const float pv = sqrt_rn_normal(piv);
+            lji = lane == i ? pv : sum / pv;
+            if (stores && (h || lane >= i)) blk[i] = lji;
+        } else {
+            lji = sum / pivrow[i];
+            if (stores) blk[i] = lji;
+        }
+        r2[i / 2][i & 1] = lji;  // (diagonal block, lanes above the pivot: a slot they never read)
+    }
+}
+
+template <int NT>
+__device__ void chol_blocked(float* __restrict__ L, bool& spd_ok) {
+    const int lane = (int) (threadIdx.x & 63), r31 = lane & 31, h = lane >> 5;
+#pragma unroll 1
+    for (int J = 0; J < NT; ++J) {
+        if (J > 0) {
+#pragma unroll 1
+            for (int I = J; I < NT; ++I) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float* rowI = L + roff(I * 32 + r31) + 4 * h;
+                const float* rowJ = L + roff(J * 32 + r31) + 4 * h;
+#pragma unroll 1
+                for (int K = 0; K < J; ++K) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(rowI + K * 32 + 8 * t);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(rowJ + K * 32 + 8 * t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {  // accumulator register r of lane l: row (r&3) + 8 (r>>2) + 4 h, column r31
+                    const int row = I * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, col = J * 32 + r31;
+                    if (row >= col) L[roff(row) + col] = sub_rn(L[roff(row) + col], acc[r]);
+                }
+            }
+            __syncthreads();
+        }
+        chol_panel_pass<true>(L, J, J, J + 1 < NT ? J + 1 : -1, spd_ok);
+        __syncthreads();
+#pragma unroll 1
+        for (int I0 = J + 2; I0 < NT; I0 += 2) chol_panel_pass<false>(L, J, I0, I0 + 1 < NT ? I0 + 1 : -1, spd_ok);
+        __syncthreads();
+    }
+}
+
 // LDS image -> + lambda, Cholesky, two triangular solves, Y[seg] <- solution.
 template <int NT>
 __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
@@ -141,7 +244,7 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
         }
         return;
     }
-    for (int i = (int) lane; i < k; i += 64) L[roff(i) + i] = add_rn(L[roff(i) + i], a.lambda);
+    for (int i = (int) lane; i < KP; i += 64) L[roff(i) + i] = i < k ? add_rn(L[roff(i) + i], a.lambda) : 1.0f;  // rows k.. : identity
     __syncthreads();
 
     // Left-looking Cholesky on the lower triangle, row i at a time (the reference's choldc1 loop,
@@ -149,7 +252,11 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     // L[j][i] = sum / p.  The dot product over q runs in four independent partial sums (the
     // reference's single accumulator would be a 64-deep dependent chain per row); products and sums
     // stay unfused.  Same arithmetic in both variants below, so they agree bit for bit.
-    if constexpr (NT <= 2) {
+    if constexpr (NT >= 2 && kBlockedCholesky) {
+        bool spd_ok = true;
+        chol_blocked<NT>(L, spd_ok);
+        if (lane == 0 && !spd_ok) atomicAdd(a.spd_fail, 1u);
+    } else if constexpr (NT <= 2) {
         // k <= 64: lane j keeps its own row j in registers (static indices after full unrolling), so
         // only row i -- the same for every lane -- is read from LDS, as broadcast ds_read_b128 of
         // whole 4-column groups; the up to three columns past the last whole group come from lane
@@ -280,6 +387,8 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     if ((int) lane < k) y[lane] = z0;
     if (NT > 2 && (int) lane + 64 < k) y[lane + 64] = z1;
 }
+
+
 
 template <int NT>
 __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {

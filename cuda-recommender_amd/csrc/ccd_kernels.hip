@@ -155,12 +155,10 @@ struct FlatArgs {
     uint32_t panel_rows;
     uint32_t gather_len;
     uint32_t nne;
-    uint32_t nseg;  // real segments
     uint64_t nnz;  // plain layout: elements at or beyond nnz are padding (cache panels: = padded nnz)
     const void* gather;
     const void* perseg;
-    float2* part;   // DENSE [npanels * nseg]: (g, h) of virtual segment (panel, segment), written by the span holding its
-                    // head; slots of empty virtual segments stay zero for ever, so the finalize reads them without a lookup
+    float2* part;   // [nne] (g, h) of every non-empty virtual segment, written by the span holding its head
     float2* carry;  // [nspans] (g, h) of a span's leading run that continues an earlier span's segment
     int add;
 };
@@ -225,26 +223,15 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     // The workgroup touches a contiguous window of ranks; stage their per-segment operands next to
     // the slice so that segmented tiles read LDS instead of chasing seg_of_rank -> perseg through L2.
     P* __restrict__ ps_lds = reinterpret_cast<P*>(lds_raw + (((size_t) a.panel_rows + 1) * sizeof(G) + 15) / 16 * 16);
-    // ... and their segment ids (the partial sums go to the dense slot (panel, segment))
-    uint32_t* __restrict__ seg_lds = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(ps_lds) +
-                                                                 (TR::kPerSeg ? (size_t) kPerSegLdsCap * sizeof(P) : 0));
     uint32_t win_base = 0;
-    uint32_t my_panel = 0;  // panel of this wavefront's span (wave-uniform)
-    if constexpr (LDS) {
+    if constexpr (LDS && TR::kPerSeg) {
         const uint32_t first = blockIdx.x * (BLOCK / 64);
         const uint32_t rb0 = a.hpre[(size_t) first * span_words];
         win_base = rb0 > 0 ? rb0 - 1 : 0;
         const uint32_t win_end = a.hpre[(size_t) (first + BLOCK / 64) * span_words];  // heads before the next chunk
         uint32_t cnt = win_end - win_base;
         if (cnt > kPerSegLdsCap) cnt = kPerSegLdsCap;
-        for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) {
-            const uint32_t sg = a.seg_of_rank[win_base + j];
-            if constexpr (TR::kPerSeg) ps_lds[j] = perseg[sg];
-            if constexpr (TR::kDot) seg_lds[j] = sg;
-        }
-        my_panel = a.wg_panel[blockIdx.x];
-    } else {
-        if (a.panel_rows && span < a.nspans) my_panel = a.wg_panel[span];  // cache panels: one entry per span
+        for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) ps_lds[j] = perseg[a.seg_of_rank[win_base + j]];
     }
     if constexpr (LDS) __syncthreads();
     if (span >= a.nspans) return;
@@ -255,15 +242,6 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
             else if (rl < kPerSegLdsCap) return ps_lds[rl];
         }
         return perseg[a.seg_of_rank[r]];
-    };
-    float2* __restrict__ part_panel = a.part + (size_t) my_panel * a.nseg;
-    auto part_slot = [&](uint32_t r) -> float2* {  // dense slot of the virtual segment with rank r
-        if constexpr (LDS) {
-            const uint32_t rl = r - win_base;
-            if constexpr (!PSCHK) return part_panel + seg_lds[rl];
-            else if (rl < kPerSegLdsCap) return part_panel + seg_lds[rl];
-        }
-        return part_panel + a.seg_of_rank[r];
     };
     const uint64_t start = (uint64_t) span * a.tiles_per_span * kTileElems;
 
@@ -378,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                         if (!seen) {
                             fg = ag; fh = ah; seen = true;
                         } else {  // head..head inside one lane: started in this span by construction
-                            *part_slot(close1 - 1) = make_float2(ag, ah);
+                            a.part[close1 - 1] = make_float2(ag, ah);
                         }
                         ++close1;
                         ag = 0.f; ah = 0.f;
@@ -398,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                 if (seen) {  // this lane's first head closes the segment of rank r1 - 1
                     const float tg = eg + fg, th = eh + fh;
                     if (r1 > rank_base) {  // it started inside this span: we own its slot
-                        *part_slot(r1 - 1) = make_float2(tg, th);
+                        a.part[r1 - 1] = make_float2(tg, th);
                     } else {  // it started in an earlier span: this is the span's head carry
                         a.carry[span] = make_float2(tg, th);
                     }
@@ -427,7 +405,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         const float tg = open_spread ? wave_sum(og) : og, th = open_spread ? wave_sum(oh) : oh;
         if (lane == 0) {
             if (cur1 > rank_base) {  // the open segment's head lies in this span: we own its slot
-                *part_slot(cur1 - 1) = make_float2(tg, th);
+                a.part[cur1 - 1] = make_float2(tg, th);
             } else {  // the whole span is interior to one segment
                 a.carry[span] = make_float2(tg, th);
             }
@@ -453,16 +431,15 @@ struct GatherPartsArgs {
     uint32_t nseg, npanels, span_len;
     const uint32_t* ptr_v;
     const uint32_t* rank_code;  // [npanels*nseg] kNoRank for an empty virtual segment, else rank | kCarryBit
-    const float2* part;         // dense [npanels*nseg]
+    const float2* part;
     const float2* carry;
 };
 constexpr uint32_t kNoRank = 0xFFFFFFFFu, kCarryBit = 0x80000000u;
 
 // (g, h) of real segment c over panels p0, p0 + stride, ...: each virtual segment = part + carries.
-// The partial of (panel, segment) sits in the dense slot p * nseg + c (zero for an empty pair), so the
-// two loads of a lookup -- the partial and the rank word, whose carry bit says whether the segment runs into
-// later spans (rare; only then are its pointers read) -- are independent of each other and coalesced over
-// the segments; kBatch panels are in flight at a time.  The additions stay in panel order.
+// A lookup is rank -> part (two dependent loads; the carry bit says whether the segment runs into
+// later spans -- rare -- and only then are its pointers read), issued for kBatch panels at a time.
+// The additions stay in panel order.
 __device__ __forceinline__ void segment_sums(const GatherPartsArgs& a, uint32_t c, uint32_t p0, uint32_t stride,
                                              float& g, float& h) {
     constexpr int kBatch = 5;
@@ -477,10 +454,7 @@ __device__ __forceinline__ void segment_sums(const GatherPartsArgs& a, uint32_t 
         }
         float2 pp[kBatch];
 #pragma unroll
-        for (int q = 0; q < kBatch; ++q) {
-            const uint32_t p = pb + q * stride;
-            pp[q] = p < a.npanels ? a.part[(size_t) p * a.nseg + c] : make_float2(0.f, 0.f);
-        }
+        for (int q = 0; q < kBatch; ++q) pp[q] = r[q] != kNoRank ? a.part[r[q] & ~kCarryBit] : make_float2(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
             if (r[q] != kNoRank) {
@@ -701,7 +675,7 @@ int launch_flat_t(const FlatArgs& a, uint32_t grid, size_t lds_bytes, hipStream_
 
 template <int MODE, int BLOCK>
 int launch_flat_lds(const SegStreamDev& s, const FlatArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
-    if (s.max_wg_ranks > kPerSegLdsCap)  // the window holds per-segment operands and / or segment ids
+    if (ModeTraits<MODE>::kPerSeg && s.max_wg_ranks > kPerSegLdsCap)
         return launch_flat_t<MODE, true, BLOCK, true>(a, grid, lds_bytes, st);
     return launch_flat_t<MODE, true, BLOCK, false>(a, grid, lds_bytes, st);
 }
@@ -713,7 +687,6 @@ int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
         return launch_flat_t<MODE, false, kBlock, false>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), 0, st);
     size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(G) + 15) / 16 * 16;
     if (ModeTraits<MODE>::kPerSeg) lds_bytes += (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
-    if (ModeTraits<MODE>::kDot) lds_bytes += (size_t) kPerSegLdsCap * sizeof(uint32_t);
     const uint32_t grid = s.nspans / s.spans_per_wg;
     switch (s.spans_per_wg) {
         case 4: return launch_flat_lds<MODE, 256>(s, a, grid, lds_bytes, st);
@@ -729,7 +702,7 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
     a.idx = s.lds_panels ? static_cast<const void*>(s.idx16) : static_cast<const void*>(s.idx);
     a.val = s.val; a.flags32 = s.flags32; a.hpre = s.hpre; a.seg_of_rank = s.seg_of_rank;
     a.wg_panel = s.wg_panel; a.nspans = s.nspans;
-    a.tiles_per_span = s.tiles_per_span; a.panel_rows = s.panel_rows; a.gather_len = s.gather_len; a.nne = s.nne; a.nseg = s.nseg;
+    a.tiles_per_span = s.tiles_per_span; a.panel_rows = s.panel_rows; a.gather_len = s.gather_len; a.nne = s.nne;
     // cache panels: padding sits at every panel's end and gathers a zero, so no tile is masked by position
     a.nnz = (s.panel_rows && !s.lds_panels) ? s.padded_nnz : s.nnz; a.gather = gather; a.perseg = perseg; a.part = s.part;
     a.carry = s.carry; a.add = add;

@@ -47,7 +47,7 @@ struct SegStreamDev {
     unsigned long long* wgacc = nullptr;       // [workgroups][2 * panel_rows] fixed-point (g, h) slabs
     const uint32_t* wg_lo = nullptr;           // [npanels + 1] first workgroup of every panel
     // reduction scratch written by the flat kernels
-    float2* part = nullptr;    // dense [npanels * nseg]: (g, h) of virtual segment (panel, segment); zero where empty
+    float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
     float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run
 };
 

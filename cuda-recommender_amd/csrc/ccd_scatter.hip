@@ -112,43 +112,54 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     const u32x4* __restrict__ s4 = reinterpret_cast<const u32x4*>(a.segid + start) + lane;
     f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
     const G* __restrict__ gop = static_cast<const G*>(a.global_op);
-    u16x4 ln = __builtin_nontemporal_load(l4);
-    u32x4 sn = __builtin_nontemporal_load(s4);
-    f32x4 vn = __builtin_nontemporal_load(v4);
-    for (uint32_t t = 0; t < a.tiles_per_span; ++t) {
-        const u16x4 li = ln;
-        const u32x4 si = sn;
-        const f32x4 v = vn;
-        if (t + 1 < a.tiles_per_span) {
-            ln = __builtin_nontemporal_load(l4 + (t + 1) * 64);
-            sn = __builtin_nontemporal_load(s4 + (t + 1) * 64);
-            vn = __builtin_nontemporal_load(v4 + (t + 1) * 64);
-        }
-        G gp[4];
+    // Software pipeline over three statically named register sets (A, B, C; tiles_per_span is a multiple of 3):
+    // the streams (local index, segment id, value) run THREE tiles ahead at issue, the gather of the streamed
+    // operand ONE tile ahead (its addresses are segment ids that arrived two tiles ago), so every wait is for
+    // loads issued at least a whole tile earlier, and no register is ever rotated through a move (a move of a
+    // register that is still in flight is a wait).  Left to itself the compiler sinks every gather to its use
+    // behind the LDS atomics of the previous element and waits vmcnt(0) four times per tile -- four serialized L2
+    // round trips that also drain the prefetch: 0.65 ms per pass instead of 0.41.  Straight-line body, no branch
+    // (a branch merges two wait counts into the smaller one); loads past the span's end are clamped re-reads.
+    struct Tile { u16x4 l; u32x4 s; f32x4 v; };
+    const uint32_t nt = a.tiles_per_span;
+    auto stream = [&](uint32_t t) {
+        const uint32_t tc = t < nt ? t : nt - 1;
+        Tile x;
+        x.l = __builtin_nontemporal_load(l4 + tc * 64);
+        x.s = __builtin_nontemporal_load(s4 + tc * 64);
+        x.v = __builtin_nontemporal_load(v4 + tc * 64);
+        return x;
+    };
+    struct Gath { G g[4]; };
+    auto gather = [&](const Tile& x) {
+        Gath r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gp[e] = gop[si[e]];  // ascending inside a panel: a few cache lines per wave
+        for (int e = 0; e < 4; ++e) r.g[e] = gop[x.s[e]];  // ascending inside a panel: a few cache lines per wave
+        return r;
+    };
+    auto compute = [&](const Tile& x, const Gath& gp, uint32_t t) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t l = li[e];
+            const uint32_t l = x.l[e];
             float gc, hc;
             if constexpr (MODE == SM_V) {
                 const float2 sp = slice[l];
-                o[e] = add_rn(sub_rn(v[e], mul_rn(gp[e].x, sp.x)), mul_rn(gp[e].y, sp.y));
-                gc = gp[e].y * o[e];
-                hc = gp[e].y * gp[e].y;
+                o[e] = add_rn(sub_rn(x.v[e], mul_rn(gp.g[e].x, sp.x)), mul_rn(gp.g[e].y, sp.y));
+                gc = gp.g[e].y * o[e];
+                hc = gp.g[e].y * gp.g[e].y;
             } else if constexpr (MODE == SM_U) {
                 const float2 sp = slice[l];
-                o[e] = add_rn(sub_rn(v[e], mul_rn(gp[e].x, sp.x)), mul_rn(gp[e].y, sp.y));
-                gc = gp[e].z * o[e];
-                hc = gp[e].z * gp[e].z;
+                o[e] = add_rn(sub_rn(x.v[e], mul_rn(gp.g[e].x, sp.x)), mul_rn(gp.g[e].y, sp.y));
+                gc = gp.g[e].z * o[e];
+                hc = gp.g[e].z * gp.g[e].z;
             } else if constexpr (MODE == SM_SWEEP) {
-                o[e] = v[e];
-                gc = gp[e] * v[e];
-                hc = gp[e] * gp[e];
+                o[e] = x.v[e];
+                gc = gp.g[e] * x.v[e];
+                hc = gp.g[e] * gp.g[e];
             } else {
-                const float prod = mul_rn(slice[l], gp[e]);
-                o[e] = a.add ? add_rn(v[e], prod) : sub_rn(v[e], prod);
+                const float prod = mul_rn(slice[l], gp.g[e]);
+                o[e] = a.add ? add_rn(x.v[e], prod) : sub_rn(x.v[e], prod);
                 gc = 0.f; hc = 0.f;
             }
             if constexpr (TR::kAcc) {
@@ -157,6 +168,25 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
             }
         }
         if constexpr (TR::kWrite) __builtin_nontemporal_store(o, v4 + t * 64);
+    };
+    Tile A = stream(0), B = stream(1), C = stream(2);
+    Gath ga = gather(A), gb, gc;
+    for (uint32_t t = 0; t < nt; t += 3) {
+        gb = gather(B);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(A, ga, t);
+        __builtin_amdgcn_sched_barrier(0);
+        A = stream(t + 3);
+        gc = gather(C);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(B, gb, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        B = stream(t + 4);
+        ga = gather(A);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(C, gc, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        C = stream(t + 5);
     }
     if constexpr (TR::kAcc) {
         __syncthreads();
@@ -205,7 +235,7 @@ int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, hipStream_t st
 }  // namespace
 
 int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st) {
-    MFX_REQUIRE(s.scatter && s.spans_per_wg == kScatBlock / 64, "launch_scatter: not a scatter layout");
+    MFX_REQUIRE(s.scatter && s.spans_per_wg == kScatBlock / 64 && s.tiles_per_span % 3 == 0, "launch_scatter: not a scatter layout");
     ScatterArgs a;
     a.lidx = s.idx16; a.segid = s.segid; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
     a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;

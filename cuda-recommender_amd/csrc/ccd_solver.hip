@@ -80,6 +80,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     const uint32_t spans_per_wg = (opt.panel_rows && opt.lds) ? std::max(1u, opt.spans_per_wg) : 1u;
     uint32_t tps = opt.tiles_per_span ? opt.tiles_per_span : pick_tiles_per_span(nnz, opt.panel_rows != 0 && opt.lds);
     if (tps & 1) ++tps;
+    if (opt.scatter) tps = std::max<uint32_t>(3u, (tps + 2) / 3 * 3);  // the scatter kernel walks a span three tiles at a time
     const uint64_t span = (uint64_t) tps * kTileElems, chunk = span * spans_per_wg;
     const size_t nv = (size_t) P * nseg;
     MFX_REQUIRE((uint64_t) P * nseg < 0x7FFFFFFFull, "panels x segments exceeds the 32-bit virtual-segment range");
@@ -161,7 +162,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     }
     const uint32_t nspans = (uint32_t) (padded / span);
     std::vector<uint32_t> wg_panel;
-    if (opt.panel_rows) {  // workgroup chunk -> panel (LDS panels: one slice per workgroup; cache panels: one entry per span)
+    if (opt.panel_rows && lds) {  // workgroup -> panel (a workgroup stages exactly one slice)
         const uint32_t nwg = nspans / spans_per_wg;
         wg_panel.assign(nwg, 0);
         uint32_t p = 0;
@@ -184,7 +185,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
         MFX_TRY(wg_lo_.alloc(wg_lo.size())); MFX_TRY(wg_lo_.upload(wg_lo.data(), wg_lo.size(), MFX_HOST, st));
         MFX_TRY(wgacc_.alloc((size_t) nwg * 2 * opt.panel_rows));
     } else {
-        MFX_TRY(part_.alloc_zero(nv ? nv : 1, st));  // dense (panel, segment) slots; empty pairs stay zero
+        MFX_TRY(part_.alloc_zero(nne ? nne : 1, st));
         MFX_TRY(carry_.alloc_zero(nspans, st));
     }
     MFX_HIP(hipStreamSynchronize(st));  // host vectors behind the uploads, temporaries behind the kernels
@@ -311,7 +312,7 @@ int SegStreamStore::build_host(uint32_t nseg, uint64_t nnz, uint32_t G, const ui
     MFX_TRY(seg_of_rank_.upload(L.seg_of_rank.data(), L.nne, MFX_HOST, st));
     MFX_TRY(wg_panel_.alloc(L.wg_panel.empty() ? 1 : L.wg_panel.size()));
     MFX_TRY(wg_panel_.upload(L.wg_panel.data(), L.wg_panel.size(), MFX_HOST, st));
-    MFX_TRY(part_.alloc_zero(nv ? nv : 1, st));  // dense (panel, segment) slots; empty pairs stay zero
+    MFX_TRY(part_.alloc_zero(L.nne ? L.nne : 1, st));
     MFX_TRY(carry_.alloc_zero(L.nspans, st));
     // the host vectors behind the async uploads must outlive the copies
     MFX_HIP(hipStreamSynchronize(st));
@@ -565,7 +566,8 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
         FlatLayoutOptions o;  // scatter: 24 B of LDS per local index (operand pair + two 64-bit accumulators)
         o.scatter = true; o.lds = true; o.spans_per_wg = 16;
         o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : 6144u, std::max<uint32_t>(G, 1u));
-        o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : 0;
+        // spans of 18 tiles when the matrix is large: a workgroup then flushes its 96 KB slab once per 74 k entries
+        o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : (nnz_ >= (32u << 20) ? 18u : 0u);
         return o;
     };
     scatter_ = scatter;

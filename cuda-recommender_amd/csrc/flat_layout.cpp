@@ -192,9 +192,8 @@ void build_flat_layout(const uint32_t* ptr, const uint32_t* idx, uint32_t nseg, 
             L.max_wg_ranks = std::max(L.max_wg_ranks, hi - lo);
         }
     }
-    // 5. workgroup chunk -> panel (LDS panels: a workgroup stages exactly one slice; cache panels: a chunk is one
-    //    span, and the kernel needs its panel to address the dense partial-sum slots)
-    if (PR) {
+    // 5. workgroup -> panel (LDS panels: a workgroup stages exactly one slice)
+    if (PR && L.lds) {
         const uint32_t nwg = L.nspans / L.spans_per_wg;
         L.wg_panel.assign(nwg, 0);
         uint32_t p = 0;

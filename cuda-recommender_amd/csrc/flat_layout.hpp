@@ -122,7 +122,7 @@ struct FlatLayoutHost {
     std::vector<uint32_t> hpre;            // [padded_nnz / 32 + 16] heads before each word (tail = nne)
     std::vector<int32_t> rank_of_seg;      // [npanels*nseg], -1 for an empty virtual segment
     std::vector<uint32_t> seg_of_rank;     // [nne] REAL segment id of each rank
-    std::vector<uint32_t> wg_panel;        // [nspans / spans_per_wg] (panel layouts; cache panels: spans_per_wg = 1)
+    std::vector<uint32_t> wg_panel;        // [nspans / spans_per_wg] (panel layout only)
     HostVec<uint32_t> idx_local;           // [padded_nnz] panel-local gathered index (pad: zero slot); empty if idx16 was asked for
     HostVec<uint16_t> idx16;               // [padded_nnz] the same as 16-bit values (FlatLayoutOptions::emit_idx16)
     HostVec<uint32_t> perm;                // [padded_nnz] input position of each stored element, ~0u for pad

@@ -2,6 +2,12 @@
 import os
 import sys
 
+# OpenMP worker threads of the CPU oracle (and of anything else in the process) must sleep between parallel
+# regions, not spin: the GPU box grants 16 cores, and spinning pools made the full-size oracle runs 5x slower
+# inside the suite than on their own.  Must be in the environment before the first OpenMP runtime loads.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 import pytest
 

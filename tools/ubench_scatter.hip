@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -137,6 +138,24 @@ int main(int argc, char** argv) {
         hr[i] = cur;
         hrr[i] = (uint32_t) (rnd() % rows);
         hc[i] = (uint16_t) (rnd() % pcols);
+    }
+    if (argc > 4) {
+        // "real" mode: draw nnz uniform (i, j) pairs of a rows x 1M matrix and lay them out exactly as the solver does --
+        // panel-major over the columns, row-major inside a panel (stable counting sort by panel of the row-sorted pairs)
+        const uint32_t cols = 1000000u, P = (cols + pcols - 1) / pcols;
+        std::vector<uint64_t> key(nnz);
+        for (uint64_t i = 0; i < nnz; ++i) key[i] = ((uint64_t) (rnd() % rows) << 32) | (uint32_t) (rnd() % cols);
+        std::sort(key.begin(), key.end());  // row-major (CSR order)
+        std::vector<uint64_t> cnt(P + 1, 0);
+        for (uint64_t i = 0; i < nnz; ++i) ++cnt[(uint32_t) key[i] / pcols + 1];
+        for (uint32_t p = 0; p < P; ++p) cnt[p + 1] += cnt[p];
+        for (uint64_t i = 0; i < nnz; ++i) {
+            const uint32_t j = (uint32_t) key[i], p = j / pcols;
+            const uint64_t d = cnt[p]++;
+            hr[d] = (uint32_t) (key[i] >> 32);
+            hc[d] = (uint16_t) (j - p * pcols);
+        }
+        printf("REAL layout: %u panels, rows ascending inside each\n", P);
     }
     CK(hipMemcpy(row, hr.data(), nnz * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(rowr, hrr.data(), nnz * 4, hipMemcpyHostToDevice));
