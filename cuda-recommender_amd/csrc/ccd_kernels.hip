@@ -559,6 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_unpermute(uint64_t n, const uint32_t
 
 // The same when every virtual segment is one run of consecutive input positions (flat_layout.hpp,
 // perm_is_runs): one wavefront per virtual segment, out[first_q[v] + k] = val[ptr_v[v] + k].
+template <bool TR>  // TR: tiles stored transposed (scatter layout): position d of the panel-major order sits at tile + 4 (d & 63) + ((d >> 6) & 3)
 __global__ __launch_bounds__(kBlock) void k_unpermute_runs(uint32_t nv, uint32_t nseg, const uint32_t* __restrict__ ptr_v,
                                                            const uint32_t* __restrict__ first_q,
                                                            const uint32_t* __restrict__ panel_end,
@@ -571,7 +572,10 @@ __global__ __launch_bounds__(kBlock) void k_unpermute_runs(uint32_t nv, uint32_t
         if (hi > pe) hi = pe;  // a panel's last virtual segment also spans the padding
         if (hi <= lo) continue;
         const uint32_t q0 = first_q[v];
-        for (uint32_t k = lane; k < hi - lo; k += 64) out[q0 + k] = val[lo + k];
+        for (uint32_t k = lane; k < hi - lo; k += 64) {
+            const uint32_t d = lo + k;
+            out[q0 + k] = val[TR ? ((d & ~255u) | ((d & 63u) << 2) | ((d >> 6) & 3u)) : d];
+        }
     }
 }
 
@@ -797,8 +801,8 @@ int launch_unpermute_runs(const SegStreamDev& s, const uint32_t* first_q, const 
     const uint32_t nv = s.npanels * s.nseg;
     if (nv == 0) return MFX_OK;
     const uint32_t blocks = std::min<uint32_t>((nv + kBlock / 64 - 1) / (kBlock / 64), 65536u);
-    hipLaunchKernelGGL(k_unpermute_runs, dim3(blocks), dim3(kBlock), 0, st, nv, s.nseg, s.ptr_v, first_q, panel_end,
-                       s.val, out);
+    if (s.scatter) hipLaunchKernelGGL(k_unpermute_runs<true>, dim3(blocks), dim3(kBlock), 0, st, nv, s.nseg, s.ptr_v, first_q, panel_end, s.val, out);
+    else hipLaunchKernelGGL(k_unpermute_runs<false>, dim3(blocks), dim3(kBlock), 0, st, nv, s.nseg, s.ptr_v, first_q, panel_end, s.val, out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }

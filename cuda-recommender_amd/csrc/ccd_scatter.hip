@@ -112,14 +112,18 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     const u32x4* __restrict__ s4 = reinterpret_cast<const u32x4*>(a.segid + start) + lane;
     f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
     const G* __restrict__ gop = static_cast<const G*>(a.global_op);
-    // Software pipeline over three statically named register sets (A, B, C; tiles_per_span is a multiple of 3):
-    // the streams (local index, segment id, value) run THREE tiles ahead at issue, the gather of the streamed
-    // operand ONE tile ahead (its addresses are segment ids that arrived two tiles ago), so every wait is for
-    // loads issued at least a whole tile earlier, and no register is ever rotated through a move (a move of a
-    // register that is still in flight is a wait).  Left to itself the compiler sinks every gather to its use
-    // behind the LDS atomics of the previous element and waits vmcnt(0) four times per tile -- four serialized L2
-    // round trips that also drain the prefetch: 0.65 ms per pass instead of 0.41.  Straight-line body, no branch
-    // (a branch merges two wait counts into the smaller one); loads past the span's end are clamped re-reads.
+    // Inside every 256-entry tile the builder stores the row-sorted entries TRANSPOSED: lane l's four elements are
+    // sorted entries l, 64 + l, 128 + l, 192 + l of the tile.  The streams keep their 16-byte-per-lane loads, and
+    // gather instruction e covers 64 CONSECUTIVE sorted entries -- ~100 rows, 7 cache lines -- so the four gathers
+    // of a tile touch disjoint quarters of its row window, each line exactly once.  (With the natural order every
+    // one of the four instructions touched all ~26 lines of the window and relied on the 32 KB L1 to hold 16 waves'
+    // windows between them: it does not, and the pass ran at 0.55-0.65 ms instead of 0.4.)
+    // Schedule: two statically named register sets (no register is rotated through a move: a move of a register
+    // that is still in flight is a wait); per tile the four gathers go out back to back, then the stream loads of
+    // the next tile, then the tile is computed.  Straight-line body, no branch (a branch merges two wait counts
+    // into the smaller one); the loads past the span's end are clamped re-reads.  The sched_barriers pin the issue
+    // order -- left to itself the compiler sinks every gather to its use behind the LDS atomics of the previous
+    // element and waits vmcnt(0) four times per tile.
     struct Tile { u16x4 l; u32x4 s; f32x4 v; };
     const uint32_t nt = a.tiles_per_span;
     auto stream = [&](uint32_t t) {
@@ -169,24 +173,19 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
         }
         if constexpr (TR::kWrite) __builtin_nontemporal_store(o, v4 + t * 64);
     };
-    Tile A = stream(0), B = stream(1), C = stream(2);
-    Gath ga = gather(A), gb, gc;
-    for (uint32_t t = 0; t < nt; t += 3) {
-        gb = gather(B);
+    Tile A = stream(0), B;
+    Gath ga, gb;
+    for (uint32_t t = 0; t < nt; t += 2) {
+        ga = gather(A);
+        B = stream(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         compute(A, ga, t);
         __builtin_amdgcn_sched_barrier(0);
-        A = stream(t + 3);
-        gc = gather(C);
+        gb = gather(B);
+        A = stream(t + 2);
         __builtin_amdgcn_sched_barrier(0);
         compute(B, gb, t + 1);
         __builtin_amdgcn_sched_barrier(0);
-        B = stream(t + 4);
-        ga = gather(A);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(C, gc, t + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        C = stream(t + 5);
     }
     if constexpr (TR::kAcc) {
         __syncthreads();
@@ -235,7 +234,7 @@ int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, hipStream_t st
 }  // namespace
 
 int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st) {
-    MFX_REQUIRE(s.scatter && s.spans_per_wg == kScatBlock / 64 && s.tiles_per_span % 3 == 0, "launch_scatter: not a scatter layout");
+    MFX_REQUIRE(s.scatter && s.spans_per_wg == kScatBlock / 64 && s.tiles_per_span % 2 == 0, "launch_scatter: not a scatter layout");
     ScatterArgs a;
     a.lidx = s.idx16; a.segid = s.segid; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
     a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;

@@ -80,14 +80,13 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     const uint32_t spans_per_wg = (opt.panel_rows && opt.lds) ? std::max(1u, opt.spans_per_wg) : 1u;
     uint32_t tps = opt.tiles_per_span ? opt.tiles_per_span : pick_tiles_per_span(nnz, opt.panel_rows != 0 && opt.lds);
     if (tps & 1) ++tps;
-    if (opt.scatter) tps = std::max<uint32_t>(3u, (tps + 2) / 3 * 3);  // the scatter kernel walks a span three tiles at a time
     const uint64_t span = (uint64_t) tps * kTileElems, chunk = span * spans_per_wg;
     const size_t nv = (size_t) P * nseg;
     MFX_REQUIRE((uint64_t) P * nseg < 0x7FFFFFFFull, "panels x segments exceeds the 32-bit virtual-segment range");
     if (opt.panel_rows && lds) MFX_REQUIRE(opt.panel_rows <= 0xFFFFu, "panel_rows must be <= 65535");
     in.npanels = P; in.panel_rows = opt.panel_rows; in.local_idx = opt.panel_rows != 0 && lds; in.idx16 = in.local_idx;
     in.pad_index = opt.panel_rows ? (lds ? opt.panel_rows : G) : 0u;
-    in.span_len = (uint32_t) span; in.chunk = chunk;
+    in.span_len = (uint32_t) span; in.chunk = chunk; in.transpose_tiles = opt.scatter;
 
     MFX_TRY(lk_check_ptr(in, st));
     DevBuf<uint32_t> cnt, S, scratch, dstart, ddelta, v_of_rank, dmax;

@@ -220,7 +220,9 @@ __global__ __launch_bounds__(kLB) void k_ranks(const uint32_t* __restrict__ ptr_
 }
 
 // One pass over the stored positions, 4 per thread.  rank -> virtual segment -> source run: no search.
-template <bool IDX16>
+// TR: transposed tiles (scatter layout) -- the thread's four stored positions tile + 4l + e hold the entries
+// tile + 64e + l of the panel-major order, so each needs its own head-count lookup.
+template <bool IDX16, bool TR>
 __global__ __launch_bounds__(kLB) void k_place(LayoutBuildIn in, uint64_t padded, const uint32_t* __restrict__ ptr_v,
                                                const uint32_t* __restrict__ first_q, const uint32_t* __restrict__ cnt,
                                                const uint32_t* __restrict__ flags32, const uint32_t* __restrict__ hpre,
@@ -228,16 +230,30 @@ __global__ __launch_bounds__(kLB) void k_place(LayoutBuildIn in, uint64_t padded
                                                float* __restrict__ val_out, uint32_t* __restrict__ seg_out) {
     const uint64_t d0 = ((uint64_t) blockIdx.x * kLB + threadIdx.x) * 4;
     if (d0 >= padded) return;
-    const uint32_t w = (uint32_t) (d0 >> 5), sh = (uint32_t) (d0 & 31);
-    const uint32_t fl = flags32[w];
-    uint32_t r1 = hpre[w] + (uint32_t) __popc(fl & ((1u << sh) - 1u));  // heads before d0
     uint32_t cur = kNone, pv = 0, cn = 0, fq = 0, pbase = 0, seg = 0;
     uint32_t oi[4], os[4];
     float ov[4];
+    uint32_t r1 = 0, fl = 0, sh = 0;
+    if constexpr (!TR) {
+        const uint32_t w = (uint32_t) (d0 >> 5);
+        sh = (uint32_t) (d0 & 31);
+        fl = flags32[w];
+        r1 = hpre[w] + (uint32_t) __popc(fl & ((1u << sh) - 1u));  // heads before d0
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        if ((fl >> (sh + e)) & 1u) ++r1;
-        const uint32_t rank = r1 - 1;  // >= 0: the first stored position is a head
+        uint32_t sd;    // position in the panel-major order
+        uint32_t rank;  // >= 0: the first stored position is a head
+        if constexpr (TR) {
+            sd = (uint32_t) (d0 & ~255ull) + 64u * e + (uint32_t) ((d0 & 255) >> 2);
+            const uint32_t w = sd >> 5, s2 = sd & 31;
+            const uint32_t f2 = flags32[w];
+            rank = hpre[w] + (uint32_t) __popc(f2 & ((2u << s2) - 1u)) - 1u;  // heads at or before sd, minus one
+        } else {
+            sd = (uint32_t) d0 + e;
+            if ((fl >> (sh + e)) & 1u) ++r1;
+            rank = r1 - 1;
+        }
         if (rank != cur) {
             cur = rank;
             const uint32_t v = v_of_rank[rank];
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(kLB) void k_place(LayoutBuildIn in, uint64_t padded
             pbase = in.local_idx ? (v / in.nseg) * in.panel_rows : 0u;
             seg = v % in.nseg;
         }
-        const uint32_t off = (uint32_t) d0 + e - pv;
+        const uint32_t off = sd - pv;
         if (off < cn) {
             const uint32_t q = fq + off;
             oi[e] = in.idx[q] - pbase;
@@ -389,8 +405,14 @@ int lk_place(const LayoutBuildIn& in, uint64_t padded, const uint32_t* ptr_v, co
              const uint32_t* flags32, const uint32_t* hpre, const uint32_t* v_of_rank, void* idx_out, float* val_out,
              uint32_t* seg_out, hipStream_t st) {
     const dim3 grid(grid_for(padded, kLB * 4)), block(kLB);
-    if (in.idx16) hipLaunchKernelGGL(k_place<true>, grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out, seg_out);
-    else hipLaunchKernelGGL(k_place<false>, grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out, seg_out);
+    if (in.transpose_tiles) {
+        MFX_REQUIRE(in.idx16, "transposed tiles come with 16-bit local indices");
+        hipLaunchKernelGGL((k_place<true, true>), grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out, seg_out);
+    } else if (in.idx16) {
+        hipLaunchKernelGGL((k_place<true, false>), grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out, seg_out);
+    } else {
+        hipLaunchKernelGGL((k_place<false, false>), grid, block, 0, st, in, padded, ptr_v, first_q, cnt, flags32, hpre, v_of_rank, idx_out, val_out, seg_out);
+    }
     LK_LAUNCH_CHECK();
     return MFX_OK;
 }

@@ -34,6 +34,7 @@ struct LayoutBuildIn {
     bool local_idx = false;    // LDS panels: stored index = idx - panel * PR
     bool idx16 = false;        // ... stored as uint16
     uint32_t pad_index = 0;
+    bool transpose_tiles = false;  // scatter layout: stored position tile + 4l + e holds entry tile + 64e + l of the panel-major order
     uint32_t span_len = 0;     // tiles_per_span * 256
     uint64_t chunk = 0;        // span_len * spans_per_wg: panels are padded to whole chunks
     const uint32_t* ptr = nullptr;  // device, [nseg + 1]

@@ -28,6 +28,15 @@ open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
 als = [l for l in open(os.path.join(src, "bench_als.log")) if l.startswith("{")]
 if als:
     open(os.path.join(dst, f"{tag}_bench_als.json"), "w").write(als[-1])
+for extra, name in (("bench_als128.log", "bench_als_k128"), ("bench_shard.log", "bench_shard")):
+    pth = os.path.join(src, extra)
+    if os.path.exists(pth):
+        ls = [l for l in open(pth) if l.startswith("{")]
+        if ls:
+            open(os.path.join(dst, f"{tag}_{name}.json"), "w").write(ls[-1])
+for f in newest("stats_shard", "*kernel_stats.csv"):
+    rd = list(csv.reader(open(f)))
+    csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats_shard.csv"), "w")).writerows([rd[0]] + [r for r in rd[1:] if "mfx" in r[0]])
 bench = json.loads(line)
 Z = int(bench["config"]["nnz_global"])
 def mean(dirname, kern, ctr):
