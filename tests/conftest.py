@@ -20,6 +20,28 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 CASES = ("tiny", "small", "edge")
 
 
+# Some libraries narrow the CPU affinity of the thread that initialises them (RCCL pins around its GPU's NUMA
+# node) and every thread created afterwards inherits the narrow mask -- the oracle's OpenMP workers among them:
+# the full-size ALS oracle run took 240 s inside the suite against 41 s on its own.  Put the mask of every thread
+# of the process back before each test.
+_AFFINITY0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+
+
+@pytest.fixture(autouse=True)
+def _restore_cpu_affinity():
+    if _AFFINITY0 is not None:
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    if os.sched_getaffinity(int(tid)) != _AFFINITY0:
+                        os.sched_setaffinity(int(tid), _AFFINITY0)
+                except OSError:
+                    pass
+        except OSError:
+            pass
+    yield
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

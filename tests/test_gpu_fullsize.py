@@ -232,7 +232,9 @@ def test_fullsize_k64_als_vs_oracle(big):
     s.close()
     t1 = time.time()
     Wr, Hr, rmse_ref, _ = orc.als(d, H0, K, 0.05, 1, orc.max_threads())
-    print(f"[als full-size] data + gpu {t1 - t0:.1f} s, oracle {time.time() - t1:.1f} s on {orc.max_threads()} threads")
+    import os
+    print(f"[als full-size] data + gpu {t1 - t0:.1f} s, oracle {time.time() - t1:.1f} s on {orc.max_threads()} threads, "
+          f"affinity {len(os.sched_getaffinity(0))} cpus")
     assert abs(rep[0].rmse - rmse_ref[0]) < 1e-4, (rep[0].rmse, rmse_ref)
     scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
     assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale
