@@ -45,8 +45,7 @@ struct SegStreamDev {
     bool scatter = false;
     const uint32_t* segid = nullptr;           // [padded nnz] segment of every stored element (pad: 0)
     unsigned long long* wgacc = nullptr;       // [workgroups][2 * panel_rows] fixed-point (g, h) slabs
-    const uint32_t* wg_lo = nullptr;           // [npanels + 1] first workgroup chunk of every panel
-    const uint32_t* wg_chunk = nullptr;        // [workgroups] chunk processed by workgroup b (XCD-aware order), or nullptr = b
+    const uint32_t* wg_lo = nullptr;           // [npanels + 1] first workgroup of every panel
     // reduction scratch written by the flat kernels
     float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
     float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run
@@ -75,8 +74,6 @@ enum ScatterMode : int {
     SM_RESID = 3,  // slice float y, streamed float x: val (+/-)= y*x
 };
 int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st);
-// out[c] = segment id of the first stored element of chunk c (device arrays)
-int scatter_chunk_first_seg(const uint32_t* segid, uint64_t chunk_elems, uint32_t nchunks, uint32_t* out, hipStream_t st);
 // slabs of a scatter pass -> dense gh[0..G) = g, gh[G..2G) = h over the local dimension (G = s.gather_len)
 int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st);
 

@@ -22,8 +22,20 @@
 //     non-deterministic and 4x slower (same profile: 1.39 ms vs 0.34 ms).
 // Every workgroup flushes its accumulators to its own slab; k_scatter_combine adds the slabs of a panel
 // (integers: any order gives the same bits) and converts to the dense fp32 (g, h) that the ordinary
-// finalize / all-reduce path takes.  Measured (microbenchmark of exactly this shape): 0.40-0.42 ms per
-// pass against 0.93 ms for cache panels.
+// finalize / all-reduce path takes.
+//
+// Measured on the shard shape (k = 128): 0.51 ms (column sums, 8-byte streamed operand) / 0.66 ms (row sums,
+// 16-byte operand) per pass against 0.85 / 0.93 ms for cache panels; 244 -> 160 ms per outer iteration.  What
+// bounds it now is the vector-memory path of the CU (~10 B/clk/CU whether a load is served by HBM, the Infinity
+// Cache or L2): per non-zero 10 B of streams + 4 B stored + the L1 line fills of the streamed operand, which at
+// 0.6 entries per (panel, row) pair cost as much as the streams themselves (npanels x |operand| = 1.6 / 3.3 GB per
+// pass).  Tried and dropped, all measured on that shape: a deeper software pipeline (gathers a tile ahead, three
+// register sets: 0.52 / 0.67 ms -- latency is not the bound); an XCD-aware workgroup order that keeps every XCD's
+// slice of the operand in its L2 across panels (workgroup b does land on XCD b % 8, tools/ubench_xcd.hip, but the
+// passes slowed to 0.62 / 0.74 ms: L2 hits do not relieve the path); the natural order inside a tile (every
+// gather instruction then touches all ~26 lines of the tile's row window and 16 waves' windows do not fit the
+// 32 KB L1: 0.55-0.65 / 0.75-0.82 ms).  The first microbenchmark (profiles/r02_ubench_scatter.txt, 0.40 ms) used
+// a denser synthetic gap pattern than the real layout; on the real layout it measures 0.49 ms.
 //
 // The per-element arithmetic is the reference's (unfused multiply, subtract, multiply, add) as in the flat
 // kernel, so both residual copies keep holding bit-identical values whichever kernel updates them.
@@ -62,8 +74,7 @@ struct ScatterArgs {
     const uint16_t* lidx;     // [padded] local index inside the panel (pad: panel_rows)
     const uint32_t* segid;    // [padded] id of the streamed dimension (row of a row-major copy), ascending inside a panel
     float* val;               // [padded] residual copy
-    const uint32_t* wg_panel; // [chunks]
-    const uint32_t* wg_chunk; // [workgroups] chunk of workgroup b, or nullptr = b
+    const uint32_t* wg_panel; // [workgroups]
     uint32_t tiles_per_span, panel_rows, local_len;
     const void* slice_src;    // operands of the local dimension, [local_len]
     const void* global_op;    // operands of the streamed dimension, indexed by segid
@@ -93,13 +104,7 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     S* __restrict__ slice = reinterpret_cast<S*>(lds_raw);
     unsigned long long* __restrict__ acc = reinterpret_cast<unsigned long long*>(lds_raw + scat_slice_bytes<MODE>(a.panel_rows));
     const uint32_t pr = a.panel_rows;
-    // Workgroup -> chunk through a table that deals the chunks so that workgroups b, b + 8, b + 16, ... -- which the
-    // dispatcher is observed to place on one XCD -- stream the SAME slice of the segment-id range in every panel:
-    // that XCD's 4 MB L2 then keeps its slice of the streamed operand (1/8 of it: 1.3-2 MB) across all panels,
-    // instead of every panel pass re-fetching the whole operand from the Infinity Cache (npanels x |operand| =
-    // 1.6 / 3.3 GB per pass next to 1.75 GB of streams).  Placement only changes speed, never results.
-    const uint32_t chunk = a.wg_chunk ? a.wg_chunk[blockIdx.x] : blockIdx.x;
-    const uint32_t panel = a.wg_panel[chunk];
+    const uint32_t panel = a.wg_panel[blockIdx.x];
     const uint32_t gbase = panel * pr;
     const uint32_t cnt = a.local_len - gbase < pr ? a.local_len - gbase : pr;
     if constexpr (TR::kSlice) {
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t span = chunk * (kScatBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t span = blockIdx.x * (kScatBlock / 64) + (threadIdx.x >> 6);
     const uint64_t start = (uint64_t) span * a.tiles_per_span * 256;
     const u16x4* __restrict__ l4 = reinterpret_cast<const u16x4*>(a.lidx + start) + lane;
     const u32x4* __restrict__ s4 = reinterpret_cast<const u32x4*>(a.segid + start) + lane;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     }
     if constexpr (TR::kAcc) {
         __syncthreads();
-        unsigned long long* __restrict__ dst = a.wgacc + (size_t) chunk * 2 * pr;
+        unsigned long long* __restrict__ dst = a.wgacc + (size_t) blockIdx.x * 2 * pr;
         for (uint32_t i = threadIdx.x; i < 2 * pr; i += kScatBlock) dst[i] = acc[i];
     }
 }
@@ -216,11 +221,6 @@ __global__ __launch_bounds__(256) void k_scatter_combine(uint32_t G, uint32_t pr
     constexpr double inv = 1.0 / 68719476736.0;
     gh[c] = (float) ((double) (long long) g * inv);
     gh[G + c] = (float) ((double) (long long) h * inv);
-}
-
-__global__ void k_chunk_first_seg(const uint32_t* __restrict__ segid, uint64_t chunk_elems, uint32_t nchunks, uint32_t* __restrict__ out) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < nchunks) out[c] = segid[(uint64_t) c * chunk_elems];  // (transposed tiles: position 0 of a tile is its first sorted entry)
 }
 
 template <int MODE>
@@ -248,7 +248,7 @@ int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, hipStream_t st
 int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st) {
     MFX_REQUIRE(s.scatter && s.spans_per_wg == kScatBlock / 64 && s.tiles_per_span % 2 == 0, "launch_scatter: not a scatter layout");
     ScatterArgs a;
-    a.lidx = s.idx16; a.segid = s.segid; a.val = s.val; a.wg_panel = s.wg_panel; a.wg_chunk = s.wg_chunk; a.tiles_per_span = s.tiles_per_span;
+    a.lidx = s.idx16; a.segid = s.segid; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
     a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;
     a.add = add;
     switch (mode) {
@@ -258,13 +258,6 @@ int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_sr
         case SM_RESID: return launch_scatter_t<SM_RESID>(s, a, st);
         default: return fail(MFX_ERR_INVALID, "launch_scatter: bad mode %d", (int) mode);
     }
-}
-
-int scatter_chunk_first_seg(const uint32_t* segid, uint64_t chunk_elems, uint32_t nchunks, uint32_t* out, hipStream_t st) {
-    if (nchunks == 0) return MFX_OK;
-    hipLaunchKernelGGL(k_chunk_first_seg, dim3((nchunks + 255) / 256), dim3(256), 0, st, segid, chunk_elems, nchunks, out);
-    MFX_HIP(hipGetLastError());
-    return MFX_OK;
 }
 
 int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st) {

@@ -189,38 +189,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     }
     MFX_HIP(hipStreamSynchronize(st));  // host vectors behind the uploads, temporaries behind the kernels
     tm.lap("dev: placement + rest");
-    if (opt.scatter) {
-        flags32_.release(); hpre_.release(); rank_code_.release(); seg_of_rank_.release();
-        // XCD-aware workgroup order (see k_scatter): cut the segment-id range into 8 slices that hold the same number
-        // of chunk starts, bucket the chunks by the slice of their first segment id, and deal the buckets out so that
-        // workgroup b takes a chunk of slice b % 8.  Buckets that run dry are topped up from the others.
-        const uint32_t nwg = nspans / spans_per_wg;
-        DevBuf<uint32_t> dfirst;
-        std::vector<uint32_t> first(nwg), order(nwg);
-        MFX_TRY(dfirst.alloc(nwg ? nwg : 1));
-        MFX_TRY(scatter_chunk_first_seg(segid_.get(), chunk, nwg, dfirst.get(), st));
-        MFX_HIP(hipMemcpyAsync(first.data(), dfirst.get(), sizeof(uint32_t) * nwg, hipMemcpyDeviceToHost, st));
-        MFX_HIP(hipStreamSynchronize(st));
-        std::vector<uint32_t> sorted(first);
-        std::sort(sorted.begin(), sorted.end());
-        uint32_t cut[9];
-        for (int x = 0; x <= 8; ++x) cut[x] = x == 8 ? 0xFFFFFFFFu : (nwg ? sorted[(size_t) nwg * x / 8] : 0u);
-        std::vector<std::vector<uint32_t>> bucket(8);
-        for (uint32_t c = 0; c < nwg; ++c) {
-            int x = 0;
-            while (x < 7 && first[c] >= cut[x + 1]) ++x;
-            bucket[x].push_back(c);
-        }
-        size_t taken[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t b = 0; b < nwg; ++b) {
-            int x = (int) (b % 8);
-            for (int tries = 0; tries < 8 && taken[x] >= bucket[x].size(); ++tries) x = (x + 1) % 8;
-            order[b] = bucket[x][taken[x]++];
-        }
-        MFX_TRY(wg_chunk_.alloc(nwg ? nwg : 1));
-        MFX_TRY(wg_chunk_.upload(order.data(), nwg, MFX_HOST, st));
-        MFX_HIP(hipStreamSynchronize(st));
-    }
+    if (opt.scatter) { flags32_.release(); hpre_.release(); rank_code_.release(); seg_of_rank_.release(); }
 
     layout_ = FlatLayoutHost();  // scalars only: the arrays live in HBM
     layout_.nseg = nseg; layout_.gather_len = G; layout_.npanels = P; layout_.panel_rows = opt.panel_rows; layout_.lds = lds;
@@ -238,7 +207,6 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     view.wg_panel = wg_panel_.get(); view.perm = nullptr; view.part = part_.get();
     view.carry = carry_.get();
     view.scatter = opt.scatter; view.segid = segid_.get(); view.wgacc = wgacc_.get(); view.wg_lo = wg_lo_.get();
-    view.wg_chunk = opt.scatter && !getenv("MFX_SCATTER_NO_XCD") ? wg_chunk_.get() : nullptr;
     *done = true;
     return MFX_OK;
 }

@@ -41,7 +41,7 @@ private:
     DevBuf<float2> part_, carry_;
     DevBuf<uint32_t> rank_code_;
     DevBuf<uint16_t> idx16_;
-    DevBuf<uint32_t> segid_, wg_lo_, wg_chunk_; // scatter layout
+    DevBuf<uint32_t> segid_, wg_lo_;           // scatter layout
     DevBuf<unsigned long long> wgacc_;
     // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
     std::vector<uint32_t> first_q_host_, panel_end_host_;
