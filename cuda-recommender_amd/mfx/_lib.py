@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libmfx.so")
+LIB_PATH = os.environ.get("MFX_LIB_PATH") or os.path.join(_PKG, "libmfx.so")  # (override: A/B builds of the library)
 
 MFX_HOST, MFX_DEVICE = 0, 1
 MFX_COMM_ID_BYTES = 128
