@@ -16,9 +16,6 @@
 namespace mfx {
 namespace {
 
-#ifndef MFX_VAL_STORE_SC1
-#define MFX_VAL_STORE_SC1 0
-#endif
 constexpr int kBlock = 256;  // 4 wavefronts
 constexpr uint32_t kPerSegLdsCap = 1024;  // per-segment operands staged in LDS per workgroup
 
@@ -395,15 +392,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         }
         if constexpr (TR::kWrite) {
             if (!partial) {
-#if MFX_VAL_STORE_SC1
-                {   // write-through: the residual never waits in L2 for the write-back at the kernel boundary
-                    const f32x4 ov = {vo[0], vo[1], vo[2], vo[3]};
-                    f32x4* dstp = val4 + tile * 64;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dstp), "v"(ov) : "memory");
-                }
-#else
-                __builtin_nontemporal_store(f32x4{vo[0], vo[1], vo[2], vo[3]}, val4 + tile * 64);
-#endif
+__builtin_nontemporal_store(f32x4{vo[0], vo[1], vo[2], vo[3]}, val4 + tile * 64);  // (write-through sc1 stores instead: passes +4 %, finalize +4 us)
             } else {
                 float* vp = a.val + e0;
 #pragma unroll

@@ -291,7 +291,8 @@ def test_sharded_path_single_rank_rccl(mfx, medium):
     assert [r.rmse for r in r0] == [r.rmse for r in r1]
 
 
-@pytest.mark.parametrize("nshards,schedule,variant,T", [(2, 1, 1, 1), (3, 1, 1, 2), (4, 0, 1, 1), (2, 0, 0, 1)])
+@pytest.mark.parametrize("nshards,schedule,variant,T", [(2, 1, 1, 1), (3, 1, 1, 2), (4, 0, 1, 1), (2, 0, 0, 1),
+                                                        (3, 1, 2, 1), (2, 1, 2, 2), (2, 0, 2, 1)])  # variant 2: scatter layout (config 5's sharded path)
 def test_sharded_solve_multi_rank_loopback(mfx, orc, medium, nshards, schedule, variant, T):
     """N user-row-block shards, one solver per shard (threads of this process, loopback communicator:
     RCCL refuses two ranks on one GPU), through the real HIP kernels: local (g,h) partials, all-reduce,

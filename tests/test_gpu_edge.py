@@ -50,6 +50,8 @@ def test_all_empty_matrix(mfx, orc):
     d = mfx.dataset.from_coo(7, 5, [], [], np.zeros(0, np.float32), [1], [2], np.array([3.0], np.float32))
     W, H, csc, csr = _check(mfx, orc, d, 3)
     assert np.all(W == 0) and np.all(H == 0)  # every row/column is empty -> exactly 0
+    W, H, csc, csr = _check(mfx, orc, d, 3, kernel_variant=2)  # scatter layout: one all-padding chunk
+    assert np.all(W == 0) and np.all(H == 0)
     Y = mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, np.ones((5, 3), np.float32), 3, 0.1)
     assert np.all(Y == 0)
 
@@ -61,7 +63,7 @@ def test_tiny_shapes(mfx, orc, rows, cols, nnz):
     d = mfx.dataset.from_coo(rows, cols, key // cols, key % cols, rng.uniform(1, 5, nnz).astype(np.float32),
                              [0], [0], np.array([2.5], np.float32))
     for kw in ({}, {"panel_rows": -1}, {"panel_rows": 16}, {"panel_rows": -16}, {"schedule": 0, "kernel_variant": 0},
-               {"panel_rows": 16, "layout_build": 1}):
+               {"panel_rows": 16, "layout_build": 1}, {"kernel_variant": 2}, {"kernel_variant": 2, "panel_rows": 3, "schedule": 0}):
         _check(mfx, orc, d, 2, **kw)
 
 
