@@ -184,7 +184,7 @@ def _vp(a: Optional[np.ndarray]):
 
 
 def _csx(R: RatingData) -> L.mfx_csx:
-    R.validate()
+    R.check_types()
     return L.mfx_csx(R.rows, R.cols, R.nnz, _vp(R.csc_col_ptr), _vp(R.csc_row_idx), _vp(R.csc_val),
                      _vp(R.csr_row_ptr), _vp(R.csr_col_idx), _vp(R.csr_val))
 

@@ -62,6 +62,24 @@ class RatingData:
             self.csr_row_ptr, self.csr_col_idx, self.csr_val, self.csc_col_ptr, self.csc_row_idx,
             self.csc_val, self.test_row, self.test_col, self.test_val)])
 
+    def check_types(self) -> None:
+        """What the ctypes boundary needs to be memory-safe (shapes, dtypes); the CONTENT checks -- monotone
+        pointers, indices in range -- are the library's (MFX_ERR_INVALID), not repeated here."""
+        z = self.nnz
+        if self.csr_row_ptr.shape != (self.rows + 1,) or self.csc_col_ptr.shape != (self.cols + 1,):
+            raise ValueError("pointer arrays must have rows + 1 / cols + 1 entries")
+        for a in (self.csr_col_idx, self.csc_row_idx, self.csr_val, self.csc_val):
+            if a.shape != (z,):
+                raise ValueError("index / value arrays must have nnz entries")
+        if not (self.test_row.shape == self.test_col.shape == self.test_val.shape):
+            raise ValueError("test COO arrays must have equal lengths")
+        for a in (self.csr_row_ptr, self.csr_col_idx, self.csc_col_ptr, self.csc_row_idx, self.test_row, self.test_col):
+            if a.dtype != np.uint32 or not a.flags.c_contiguous:
+                raise ValueError("index arrays must be contiguous uint32")
+        for a in (self.csr_val, self.csc_val, self.test_val):
+            if a.dtype != np.float32 or not a.flags.c_contiguous:
+                raise ValueError("value arrays must be contiguous float32")
+
     def validate(self) -> None:
         z = self.nnz
         assert self.csr_row_ptr.shape == (self.rows + 1,) and self.csc_col_ptr.shape == (self.cols + 1,)

@@ -172,8 +172,40 @@ def test_bad_arguments_are_errors(mfx):
         mfx.CcdSolver(d, None, _p(mfx, 2, panel_rows=16, wg_waves=5))
     bad = d.copy()
     bad.csc_row_idx[0] = 10 ** 6  # index out of range must be caught on the host, not fault on the GPU
-    with pytest.raises(Exception):
+    with pytest.raises(mfx.MfxError, match="out of range|index"):
         mfx.CcdSolver(bad, None, _p(mfx, 2))
+    for build in (1, 2):   # host and device layout builders both refuse it
+        with pytest.raises(mfx.MfxError):
+            mfx.CcdSolver(bad, None, _p(mfx, 2, layout_build=build))
+    with pytest.raises(mfx.MfxError):
+        mfx.CcdSolver(bad, None, _p(mfx, 2, kernel_variant=2))
+
+
+def test_out_of_range_indices_are_errors_everywhere(mfx):
+    """ALS's orientations and the test-set COO are uploaded and gathered with on the GPU, so a bad index
+    must be an MFX_ERR_INVALID on the host side, never a device fault."""
+    d = mfx.dataset.synth_ratings(50, 40, 500, seed=1)
+    for field, value in (("csr_col_idx", 40), ("csc_row_idx", 50)):
+        bad = d.copy()
+        getattr(bad, field)[3] = value
+        with pytest.raises(mfx.MfxError):
+            mfx.AlsSolver(bad, None, _p(mfx, 4))
+    for field, value in (("test_row", 50), ("test_col", 40)):
+        bad = d.copy()
+        getattr(bad, field)[0] = value
+        with pytest.raises(mfx.MfxError):
+            mfx.CcdSolver(d, mfx.test_data_of(bad), _p(mfx, 2))
+        with pytest.raises(mfx.MfxError):
+            mfx.AlsSolver(d, mfx.test_data_of(bad), _p(mfx, 4))
+    bad = d.copy()
+    bad.csr_row_ptr[5] = bad.csr_row_ptr[6] + 1   # non-monotone pointer array
+    with pytest.raises(mfx.MfxError):
+        mfx.CcdSolver(bad, None, _p(mfx, 2))
+    with pytest.raises(mfx.MfxError):
+        mfx.AlsSolver(bad, None, _p(mfx, 4))
+    with pytest.raises(mfx.MfxError):   # half-step operator: index beyond the gathered factor
+        ptr = np.array([0, 2], np.uint32); idx = np.array([0, 7], np.uint32); val = np.ones(2, np.float32)
+        mfx.als_half(ptr, idx, val, np.ones((4, 3), np.float32), 3, 0.1)
 
 
 def _shuffle_within_segments(ptr, idx, val, rng):

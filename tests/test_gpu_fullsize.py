@@ -254,3 +254,78 @@ def test_fullsize_k64_als_vs_oracle(big, tmp_path):
     assert abs(rep[0].rmse - rmse_ref[0]) < 1e-4, (rep[0].rmse, rmse_ref)
     scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
     assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale
+
+
+# ---- the other BASELINE.json configurations, at their own shapes ----------------------------------------------
+
+@pytest.mark.parametrize("rows,cols,nnz,k,t,alg", [
+    (943, 1682, 100000, 10, 5, "ccd"),        # configs[0]: MovieLens-100K shape, k = 10
+    (943, 1682, 100000, 10, 3, "als"),
+    (6040, 3706, 1000209, 40, 5, "ccd"),      # configs[1]: MovieLens-1M shape, k = 40
+    (6040, 3706, 1000209, 40, 2, "als"),
+])
+def test_movielens_shapes_vs_oracle(rows, cols, nnz, k, t, alg):
+    """configs[0] / configs[1] of BASELINE.json (synthetic ratings of the MovieLens shapes -- the data sets
+    themselves are not in the image): every outer iteration's test RMSE within 1e-4 of the oracle's, factors within
+    2e-3 of scale, at the reference's own defaults (lambda 0.05, T = 1)."""
+    import mfx
+    from oracle import oracle as orc
+    d = mfx.dataset.synth_ratings(rows, cols, nnz, seed=100 + k, skew=0.9, test_frac=0.05)
+    p = mfx.parameter()
+    p.k, p.lambda_, p.maxiter = k, 0.05, t
+    if alg == "ccd":
+        W0 = mfx.initial_col(k, rows)
+        Wr, Hr, rmse_ref, *_ = orc.ccdr1(d, W0, k, 0.05, t, 1, 2)
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), p)
+        s.set_factors(W0.copy())
+    else:
+        H0 = mfx.initial_col(cols, k)
+        Wr, Hr, rmse_ref, _ = orc.als(d, H0, k, 0.05, t, 2)
+        s = mfx.AlsSolver(d, mfx.test_data_of(d), p)
+        s.set_factors(H0.copy())
+    rep = s.iterate(t)
+    W, H = s.get_factors()
+    s.close()
+    rm = np.array([r.rmse for r in rep])
+    assert np.all(np.abs(rm - rmse_ref) < 1e-4), (rm, rmse_ref)
+    scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
+    assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale
+
+
+def test_config5_shard_vs_oracle():
+    """configs[4] (10 M x 1 M, 1e9 ratings, k = 128, row-sharded over 8 GPUs): ONE rank's shard at full size --
+    rows [0, 1.25 M) of the 10 M, all 1 M columns, 1.25e8 ratings (12.5 per column, 100 per row: the hyper-sparse
+    regime, scatter layout on both sides) -- solved stand-alone (a one-rank job over its own rows) and compared
+    with the oracle on the same arrays.  k = 8 and two outer iterations keep the oracle at a few seconds; the
+    layouts, kernels and launch shapes are those of the k = 128 run (k only sets the number of rank-one
+    passes).  Also: a second run reproduces the first bit for bit (64-bit fixed-point LDS accumulation)."""
+    import torch
+    import mfx
+    from mfx import synth_torch
+    from oracle import oracle as orc
+    rows, cols, nnz, k, t = 1250000, 1000000, 125000000, 8, 2
+    dev = synth_torch.synth_ratings_device(rows, cols, nnz, seed=5, device="cuda:0", sigma_rows=0.5, sigma_cols=1.0)
+    d = synth_torch.to_rating_data(dev)
+    W0 = mfx.initial_col(k, rows)
+    p = mfx.parameter()
+    p.k, p.lambda_, p.maxiter = k, 0.05, t
+    outs = []
+    for _ in range(2):
+        s = mfx.CcdSolver(None, None, p, device_arrays=dev)
+        info = s.layout_info()
+        assert info["csc"]["kind"] == "scatter" and info["csr"]["kind"] == "scatter", info
+        s.set_factors(W0.copy())
+        rep = s.iterate(t)
+        W, H = s.get_factors()
+        csc, csr = s.get_residual(d.nnz)
+        s.close()
+        outs.append((W, H, csc, csr, np.array([r.rmse for r in rep])))
+    del dev
+    torch.cuda.empty_cache()
+    (W, H, csc, csr, rm), second = outs
+    assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(outs[0][:4], second[:4]))
+    Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, 0.05, t, 1, orc.max_threads())
+    assert np.all(np.abs(rm - rmse_ref) < 1e-4), (rm, rmse_ref)
+    scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
+    assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale
+    assert np.abs(csc - csc_ref).max() < 1e-3 and np.abs(csr - csr_ref).max() < 1e-3
