@@ -511,6 +511,7 @@ struct FinKernelArgs {
     float2* pack2;
     const float* next_vec;
     float4* pack4;
+    bool pack4_as3;
 };
 
 template <int PL>
@@ -543,7 +544,14 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     const float x = cnt ? g / add_rn(mul_rn(a.lambda, (float) cnt), h) : 0.f;
     a.out_vec[c] = x;
     if (a.pack2) {
-        if (a.pack4) a.pack4[c] = make_float4(old.x, old.y, x, 0.f);
+        if (a.pack4) {
+            if (a.pack4_as3) {
+                float* p3 = reinterpret_cast<float*>(a.pack4) + 3 * (size_t) c;
+                p3[0] = old.x; p3[1] = old.y; p3[2] = x;
+            } else {
+                a.pack4[c] = make_float4(old.x, old.y, x, 0.f);
+            }
+        }
         // k = 1: the "next" rank is this one, so its old value is the x just written (out_vec aliases next_vec)
         a.pack2[c] = make_float2(x, a.next_vec == a.out_vec ? x : next);
     }
@@ -779,7 +787,7 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
     if (s.nseg == 0) return MFX_OK;
     FinKernelArgs a;
     a.parts = parts_of(s); a.seg_cnt = s.seg_cnt; a.gh_dense = f.gh_dense; a.cnt_override = f.cnt_override;
-    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
+    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4; a.pack4_as3 = f.pack4_as3;
     const int pl = f.gh_dense ? 1 : panel_lanes(s);
     const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
     if (pl == 16) hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, st, a);

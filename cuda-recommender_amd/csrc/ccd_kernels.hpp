@@ -97,6 +97,7 @@ struct FinalizeArgs {
     float2* pack2 = nullptr;            // in: (prev_new, cur_old); out: (cur_new, next_old)
     const float* next_vec = nullptr;    // W[t+1] / H[t+1] slice (old values)
     float4* pack4 = nullptr;            // out: (prev_new, cur_old, cur_new, 0), may be nullptr
+    bool pack4_as3 = false;             // ... stored as 12-byte triples in the same buffer (scatter u-pass: the streamed operand's line fills are what bounds it)
 };
 int launch_finalize(const SegStreamDev& s, const FinalizeArgs& a, hipStream_t st);
 

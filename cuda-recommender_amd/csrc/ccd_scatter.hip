@@ -65,7 +65,11 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
     return a - b;
 }
 
-// fp32 -> 64-bit fixed point (two's complement), scale 2^36: exact for every fp32 with |x| < 2^27
+// fp32 -> 64-bit fixed point (two's complement), scale 2^36: exact for every fp32 with |x| < 2^27.
+// (r2: a 3-instruction conversion -- fma onto 1.5 * 2^52, integer in the low mantissa bits -- instead of this
+// 9-instruction f64 -> i64 sequence changed nothing: 339 vs 345 us on the Netflix shape, 531 vs 510 us on the
+// shard.  Neither the VALU nor the LDS atomics bound the pass: tools/ubench_ldsatomic.hip measures 0.49 clk per
+// element per CU for two random ds_add_u64, a quarter of the pass's time per element.)
 __device__ __forceinline__ unsigned long long to_fixed(float x) {
     return (unsigned long long) (long long) ((double) x * 68719476736.0);
 }
@@ -82,10 +86,11 @@ struct ScatterArgs {
     int add;
 };
 
+struct F3 { float x, y, z; };  // (prev_new, cur_old, cur_new) of the streamed dimension, 12 bytes apart
 template <int MODE> struct ScatTraits;
-// the two fused passes: slice (prev_new, cur_old) of the local dimension; streamed operand float2 (V) or float4 (U)
+// the two fused passes: slice (prev_new, cur_old) of the local dimension; streamed operand float2 (V) or a 12-byte triple (U)
 template <> struct ScatTraits<SM_V>     { using S = float2; using G = float2; static constexpr bool kSlice = true,  kAcc = true,  kWrite = true; };
-template <> struct ScatTraits<SM_U>     { using S = float2; using G = float4; static constexpr bool kSlice = true,  kAcc = true,  kWrite = true; };
+template <> struct ScatTraits<SM_U>     { using S = float2; using G = F3;     static constexpr bool kSlice = true,  kAcc = true,  kWrite = true; };
 template <> struct ScatTraits<SM_SWEEP> { using S = float;  using G = float;  static constexpr bool kSlice = false, kAcc = true,  kWrite = false; };
 template <> struct ScatTraits<SM_RESID> { using S = float;  using G = float;  static constexpr bool kSlice = true,  kAcc = false, kWrite = true; };
 

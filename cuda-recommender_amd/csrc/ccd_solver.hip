@@ -656,8 +656,9 @@ int CcdSolver::rank_fused_scatter(uint32_t t) {
     PROF(KernelProfiler::K_SCAT_V, launch_scatter(SM_V, csr_.view, packB_.get(), packA_.get(), 0, st_));
     FinalizeArgs fv;
     fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next); fv.pack4 = packC_.get();
+    fv.pack4_as3 = true;  // 12-byte triples: a quarter fewer line fills of the streamed operand in the u-pass
     MFX_TRY(scatter_finalize(true, fv));
-    // u-update: stream the COLUMN-major copy; rows are local (slice packA), columns stream (packC)
+    // u-update: stream the COLUMN-major copy; rows are local (slice packA), columns stream (packC, triples)
     PROF(KernelProfiler::K_SCAT_U, launch_scatter(SM_U, csc_.view, packA_.get(), packC_.get(), 0, st_));
     FinalizeArgs fu;
     fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
