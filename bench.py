@@ -307,8 +307,11 @@ def main() -> None:
     # + fp32 value written (the contract figure above keeps SURVEY 8d's 32-bit index)
     phys = {"ccd_fused_csc_pass": 10.0 * Z + 2 * flags, "ccd_fused_csr_pass": 10.0 * Z + 2 * flags,
             "ccd_flat_sweep": 6.0 * Z + 2 * flags, "ccd_flat_resid": 10.0 * Z + 2 * flags,
-            # scatter: 16-bit local index + 32-bit segment id + fp32 value read + written
-            "ccd_scatter_v_pass": 14.0 * Z, "ccd_scatter_u_pass": 14.0 * Z, "ccd_scatter_sweep": 10.0 * Z}
+            }
+    # scatter: 16-bit local index + segment id (one-byte step + a base per tile, or 32 bits: layout kind
+    # "scatter32") + fp32 value read + written.  The v-pass streams the row-major (CSR) copy, the u-pass the other.
+    for kn, side, rw in (("ccd_scatter_v_pass", "csr", 8.0), ("ccd_scatter_u_pass", "csc", 8.0), ("ccd_scatter_sweep", "csr", 4.0)):
+        phys[kn] = (2.0 + rw + (4.0 if layout[side]["kind"] == "scatter32" else 1.0 + 4.0 / 256)) * Z
     roofline = None
     dom = None
     if ktimes:

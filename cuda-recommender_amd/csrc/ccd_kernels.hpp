@@ -43,7 +43,9 @@ struct SegStreamDev {
     // layout, read the other way round -- idx16 is the local index of the REDUCED dimension, segid the id of
     // the streamed one; no head flags / ranks / partials
     bool scatter = false;
-    const uint32_t* segid = nullptr;           // [padded nnz] segment of every stored element (pad: 0)
+    const uint32_t* segid = nullptr;           // [padded nnz] segment of every stored element (pad: 0); nullptr when the byte steps below fit
+    const uint8_t* seg_delta = nullptr;        // [padded nnz] step from the previous entry of the tile's sorted order
+    const uint32_t* tile_base = nullptr;       // [padded nnz / 256] segment of a tile's first sorted entry
     unsigned long long* wgacc = nullptr;       // [workgroups][2 * panel_rows] fixed-point (g, h) slabs
     const uint32_t* wg_lo = nullptr;           // [npanels + 1] first workgroup of every panel
     // reduction scratch written by the flat kernels

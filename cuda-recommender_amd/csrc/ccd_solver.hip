@@ -145,6 +145,14 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     MFX_TRY(lk_place(in, padded, ptr_v_.get(), first_q_dev_.get(), cnt.get(), flags32_.get(), hpre_.get(), v_of_rank.get(),
                      in.idx16 ? static_cast<void*>(idx16_.get()) : static_cast<void*>(idx_.get()), val_.get(),
                      opt.scatter ? segid_.get() : nullptr, st));
+    if (opt.scatter && !opt.scatter_ids32) {  // ids as one-byte steps + a base per tile (11 instead of 14 B per non-zero streamed)
+        MFX_TRY(seg_delta_.alloc(padded));
+        MFX_TRY(tile_base_.alloc(padded / kTileElems));
+        bool fits = false;
+        MFX_TRY(lk_delta_encode(segid_.get(), padded, seg_delta_.get(), tile_base_.get(), &fits, st));
+        if (fits) segid_.release();
+        else { seg_delta_.release(); tile_base_.release(); }  // a step above 255 somewhere: a long run of segments without an entry in some panel
+    }
     MFX_TRY(dmax.alloc_zero(1, st));
     MFX_TRY(lk_max_wg_ranks(hpre_.get(), nwords, (size_t) (chunk / 32), dmax.get(), st));
     uint32_t max_wg_ranks = 0;
@@ -206,7 +214,7 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     view.seg_of_rank = seg_of_rank_.get(); view.max_wg_ranks = max_wg_ranks;
     view.wg_panel = wg_panel_.get(); view.perm = nullptr; view.part = part_.get();
     view.carry = carry_.get();
-    view.scatter = opt.scatter; view.segid = segid_.get(); view.wgacc = wgacc_.get(); view.wg_lo = wg_lo_.get();
+    view.scatter = opt.scatter; view.segid = segid_.get(); view.seg_delta = seg_delta_.get(); view.tile_base = tile_base_.get(); view.wgacc = wgacc_.get(); view.wg_lo = wg_lo_.get();
     *done = true;
     return MFX_OK;
 }
@@ -510,13 +518,13 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // either side, so that side would fall back to L2 "cache panels") take the scatter layout on BOTH sides
     // (ccd_scatter.hip); kernel_variant = 2 forces it, panel_rows != 0 or kernel_variant = 0 rule it out.
     const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
-    bool want_scatter = p->kernel_variant == 2;
+    bool want_scatter = p->kernel_variant == 2 || p->kernel_variant == 3;  // 3: scatter with explicit 32-bit ids
     if (!want_scatter && !need_plain && p->panel_rows == 0 && p->layout_build != 1) {
         const FlatLayoutOptions a = choose_layout(*p, m_, nnz_, n_, sizeof(float4), false), b = choose_layout(*p, n_, nnz_, m_, sizeof(float2), false);
         want_scatter = (a.panel_rows && !a.lds) || (b.panel_rows && !b.lds);
     }
     int rc = build_stores(R, p, space, want_scatter);
-    if (rc != MFX_OK && want_scatter && p->kernel_variant != 2) {  // e.g. unsorted indices: the ordinary layouts take anything
+    if (rc != MFX_OK && want_scatter && p->kernel_variant != 2 && p->kernel_variant != 3) {  // e.g. unsorted indices: the ordinary layouts take anything
         csr_ = SegStreamStore(); csc_ = SegStreamStore();
         rc = build_stores(R, p, space, false);
     }
@@ -564,6 +572,7 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
         if (!scatter) return choose_layout(*p, nseg, nnz_, G, elem_bytes, need_plain);
         FlatLayoutOptions o;  // scatter: 24 B of LDS per local index (operand pair + two 64-bit accumulators)
         o.scatter = true; o.lds = true; o.spans_per_wg = 16;
+        o.scatter_ids32 = p->kernel_variant == 3;
         o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : 6144u, std::max<uint32_t>(G, 1u));
         // spans of 18 tiles when the matrix is large: a workgroup then flushes its 96 KB slab once per 74 k entries
         o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : (nnz_ >= (32u << 20) ? 18u : 0u);

@@ -41,7 +41,8 @@ private:
     DevBuf<float2> part_, carry_;
     DevBuf<uint32_t> rank_code_;
     DevBuf<uint16_t> idx16_;
-    DevBuf<uint32_t> segid_, wg_lo_;           // scatter layout
+    DevBuf<uint32_t> segid_, wg_lo_, tile_base_;  // scatter layout
+    DevBuf<uint8_t> seg_delta_;
     DevBuf<unsigned long long> wgacc_;
     // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
     std::vector<uint32_t> first_q_host_, panel_end_host_;
@@ -92,7 +93,7 @@ public:
     int set_profile(bool on);
     void layout_info(int side, int32_t out[4]) const {
         const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
-        out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.scatter ? 2 : v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
+        out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.scatter ? (v.seg_delta ? 2 : 3) : v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
     }
 
 private:

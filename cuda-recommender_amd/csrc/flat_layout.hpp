@@ -150,6 +150,7 @@ struct FlatLayoutOptions {
     // scatter layout (ccd_scatter.hip): LDS panels + an explicit per-element segment id, no flags / ranks /
     // partials; built by the device pipeline only
     bool scatter = false;
+    bool scatter_ids32 = false;   // keep the 4-byte ids even when one-byte steps would do (A/B, tests)
     const float* val = nullptr;   // input-order values for emit_val; nullptr = zeros
 };
 

@@ -295,6 +295,40 @@ __global__ __launch_bounds__(kLB) void k_max_wg_ranks(const uint32_t* __restrict
     atomicMax(out, hpre[w1] - lo);
 }
 
+
+// Scatter layout: the per-element segment ids of a tile (ascending in the tile's sorted order; padding carries 0)
+// as one base per tile + one byte per element = the step from the previous sorted entry.  One wavefront per
+// tile; tiles are stored transposed (sorted entry 64 e + l sits at tile + 4 l + e), so lane l's four bytes are
+// one 32-bit store.  Padding repeats the last real id (running maximum).  *overflow is set when a step does not
+// fit a byte; the caller then keeps the 32-bit ids.
+__global__ __launch_bounds__(kLB) void k_delta_encode(uint64_t ntiles, const uint32_t* __restrict__ seg, uint32_t* __restrict__ delta4,
+                                                      uint32_t* __restrict__ tile_base, uint32_t* __restrict__ overflow) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t tile = ((uint64_t) blockIdx.x * kLB + threadIdx.x) >> 6;
+    if (tile >= ntiles) return;
+    const uint4 s = reinterpret_cast<const uint4*>(seg + tile * 256)[lane];
+    uint32_t m[4] = {s.x, s.y, s.z, s.w};
+    uint32_t carry = 0, word = 0;
+    bool over = false;
+    for (int e = 0; e < 4; ++e) {
+        uint32_t x = m[e];                              // running maximum over the sorted order, group e
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if (lane >= (uint32_t) off && y > x) x = y;
+        }
+        if (carry > x) x = carry;
+        uint32_t prev = __shfl_up(x, 1, 64);            // the sorted predecessor: lane - 1, or the previous group's last lane
+        if (lane == 0) prev = e == 0 ? x : carry;
+        carry = __shfl(x, 63, 64);
+        const uint32_t d = x - prev;
+        over |= d > 255u;
+        word |= (d & 255u) << (8 * e);
+        if (e == 0 && lane == 0) tile_base[tile] = x;
+    }
+    delta4[tile * 64 + lane] = word;
+    if (over) atomicOr(overflow, 1u);
+}
+
 // small device words with a host mirror
 template <typename T>
 int read_word(const T* d, T* h, hipStream_t st) {
@@ -422,6 +456,21 @@ int lk_max_wg_ranks(const uint32_t* hpre, size_t nwords, size_t chunk_words, uin
     if (nchunks == 0) return MFX_OK;
     hipLaunchKernelGGL(k_max_wg_ranks, dim3(grid_for(nchunks, kLB)), dim3(kLB), 0, st, hpre, nwords, chunk_words, nchunks, out);
     LK_LAUNCH_CHECK();
+    return MFX_OK;
+}
+
+int lk_delta_encode(const uint32_t* seg, uint64_t padded, uint8_t* delta, uint32_t* tile_base, bool* fits, hipStream_t st) {
+    *fits = true;
+    const uint64_t ntiles = padded / 256;
+    if (ntiles == 0) return MFX_OK;
+    DevBuf<uint32_t> over;
+    MFX_TRY(over.alloc_zero(1, st));
+    hipLaunchKernelGGL(k_delta_encode, dim3(grid_for(ntiles * 64, kLB)), dim3(kLB), 0, st, ntiles, seg, reinterpret_cast<uint32_t*>(delta),
+                       tile_base, over.get());
+    LK_LAUNCH_CHECK();
+    uint32_t h = 0;
+    MFX_TRY(read_word(over.get(), &h, st));
+    *fits = h == 0;
     return MFX_OK;
 }
 

@@ -75,6 +75,11 @@ int lk_place(const LayoutBuildIn& in, uint64_t padded, const uint32_t* ptr_v, co
              const uint32_t* flags32, const uint32_t* hpre, const uint32_t* v_of_rank, void* idx_out, float* val_out,
              uint32_t* seg_out, hipStream_t st);
 
+// Scatter layout: seg (the uint32 ids lk_place wrote, transposed tiles) -> delta[padded] (one byte per element: the
+// step from the previous entry of the tile's sorted order) + tile_base[padded / 256] (id of the tile's first
+// entry).  *fits = false when some step exceeds 255 (delta / tile_base are then unusable).  Synchronises `st`.
+int lk_delta_encode(const uint32_t* seg, uint64_t padded, uint8_t* delta, uint32_t* tile_base, bool* fits, hipStream_t st);
+
 // max over workgroup chunks of the ranks a chunk touches (incl. the one open at its start) -> *out (device word, zeroed by the caller)
 int lk_max_wg_ranks(const uint32_t* hpre, size_t nwords, size_t chunk_words, uint32_t* out, hipStream_t st);
 

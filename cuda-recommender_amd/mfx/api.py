@@ -383,13 +383,13 @@ class CcdSolver:
         L.check(L.lib().mfx_ccd_set_profile(self.handle, 1 if on else 0))
 
     def layout_info(self):
-        """{"csc": {...}, "csr": {...}}: panels, entries per panel, kind ("lds" / "cache" / "plain"), tiles per span."""
+        """{"csc": {...}, "csr": {...}}: panels, entries per panel, kind ("lds" / "cache" / "plain" / "scatter" / "scatter32": 32-bit segment ids), tiles per span."""
         out = {}
         for side, name in ((0, "csc"), (1, "csr")):
             v = (C.c_int32 * 4)()
             L.check(L.lib().mfx_ccd_layout_info(self.handle, side, v))
             out[name] = {"panels": int(v[0]), "panel_rows": int(v[1]),
-                         "kind": "scatter" if v[2] == 2 else "lds" if v[2] else ("cache" if v[1] else "plain"),
+                         "kind": "scatter" if v[2] == 2 else "scatter32" if v[2] == 3 else "lds" if v[2] else ("cache" if v[1] else "plain"),
                          "tiles_per_span": int(v[3])}  # kind "tile": panel_rows = slice entries, tiles_per_span = segments per block
         return out
 

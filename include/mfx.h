@@ -83,7 +83,9 @@ typedef struct mfx_params {
                                   order, bit-identical to src/ALS.cpp), 1 = MFMA Gramian + Cholesky solve */
     int32_t kernel_variant;    /* 0 = wave-per-segment kernels (schedule 0 only), 1 = flat-stream kernels (default),
                                   2 = force the scatter layout (csrc/ccd_scatter.hip), which hyper-sparse shapes
-                                  get on their own: < 8 entries per (LDS panel, row / column) pair */
+                                  get on their own: < 8 entries per (LDS panel, row / column) pair;
+                                  3 = the same with explicit 32-bit segment ids in the stream (what a layout
+                                  falls back to when some one-byte step between consecutive ids overflows) */
     int32_t profile;           /* 1: bracket every launch with HIP events (mfx_*_kernel_times) */
     int32_t tiles_per_span;    /* flat-stream span length / 256; 0 = choose from nnz */
     int32_t panel_rows;        /* panels of the gathered index space. 0 = choose (LDS panels, 64 KB of LDS per
@@ -168,7 +170,7 @@ int mfx_ccd_kernel_times(mfx_ccd_t s, int cap, const char** names, double* secon
 int mfx_ccd_set_profile(mfx_ccd_t s, int on);
 /* Layout the solver chose for one residual copy (side 0 = CSC / column segments, 1 = CSR / row
  * segments): out[0] = panels, out[1] = entries per panel (0 = plain layout), out[2] = 2 scatter
- * layout / 1 LDS panels / 0 cache panels or plain, out[3] = tiles per span (tile order: segments per block).  For logs,
+ * layout (3: with 32-bit segment ids) / 1 LDS panels / 0 cache panels or plain, out[3] = tiles per span (tile order: segments per block).  For logs,
  * benchmarks and tests. */
 int mfx_ccd_layout_info(mfx_ccd_t s, int side, int32_t out[4]);
 int mfx_ccd_destroy(mfx_ccd_t s);

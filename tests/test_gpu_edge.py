@@ -134,6 +134,40 @@ def test_hyper_sparse_shard_layouts(mfx, orc):
     _check(mfx, orc, d, 2, t=2, panel_rows=-262144)   # cache panels forced, device-built
 
 
+def _kinds(mfx, d, **kw):
+    s = mfx.CcdSolver(d, None, _p(mfx, 2, **kw))
+    info = s.layout_info()
+    s.close()
+    return info["csc"]["kind"], info["csr"]["kind"]
+
+
+def test_scatter_segment_ids_as_byte_steps(mfx, orc):
+    """The scatter layout stores the id of the streamed dimension as one byte per entry (the step from the
+    previous entry of the tile's sorted order) plus one base per tile, decoded in the kernel by two packed prefix
+    scans; kernel_variant = 3 keeps the explicit 32-bit ids.  Same ids, so bit-identical factors and residuals.
+    A pattern with a run of > 255 rows without an entry falls back to the 32-bit ids on the side it concerns
+    (and only there), still with the oracle's results."""
+    d = mfx.dataset.synth_ratings(3000, 900, 60000, seed=8, skew=0.6, test_frac=0.02, empty_row_frac=0.02)
+    assert _kinds(mfx, d, kernel_variant=2) == ("scatter", "scatter") and _kinds(mfx, d, kernel_variant=3) == ("scatter32", "scatter32")
+    for kw in ({}, {"panel_rows": 150, "tiles_per_span": 2}, {"maxinneriter": 2}, {"schedule": 0}):
+        T = kw.pop("maxinneriter", 1)
+        a = _check(mfx, orc, d, 3, t=2, T=T, kernel_variant=2, **kw)
+        b = _check(mfx, orc, d, 3, t=2, T=T, kernel_variant=3, **kw)
+        assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b)), kw
+    # rows 400 .. 1399 empty: the row ids step by 1000 inside the panels of the row-major copy
+    rng = np.random.default_rng(3)
+    r = np.concatenate([rng.integers(0, 400, 9000), rng.integers(1400, 2000, 9000)])
+    c = rng.integers(0, 300, 18000)
+    key = np.unique(r * 300 + c)
+    r, c = key // 300, key % 300
+    v = rng.uniform(1, 5, r.shape[0]).astype(np.float32)
+    g = mfx.dataset.from_coo(2000, 300, r[50:], c[50:], v[50:], r[:50], c[:50], v[:50])
+    kinds = _kinds(mfx, g, kernel_variant=2)
+    assert kinds == ("scatter", "scatter32"), kinds   # the column-major copy streams column ids: dense
+    _check(mfx, orc, g, 3, t=2, kernel_variant=2)
+    _check(mfx, orc, g, 3, t=2, kernel_variant=2, panel_rows=64)
+
+
 @pytest.mark.parametrize("kw", [{}, {"schedule": 0}, {"maxinneriter": 3}, {"panel_rows": 40}, {"panel_rows": 7, "tiles_per_span": 2}])
 @pytest.mark.parametrize("name", ["tiny", "small", "edge"])
 def test_scatter_layout_on_golden(mfx, name, kw):
