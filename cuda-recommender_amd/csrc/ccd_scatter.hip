@@ -11,7 +11,7 @@
 // What this kernel does instead: SWAP THE ROLES.  A pass that needs the sums over COLUMNS streams the
 // ROW-major copy (and vice versa), stored panel-major over the columns:
 //   * the panel's columns are local (16-bit index): their operands AND their (g, h) accumulators sit in
-//     LDS (24 B per column, 6144 columns per workgroup);
+//     LDS (24 B per column, 6816 columns per workgroup: all of a CU's 160 KB);
 //   * inside a panel the entries keep the copy's row-major order, so the row operand is an ASCENDING,
 //     nearly sequential global read (a wave's 256 entries span ~400 rows = ~25 cache lines instead of
 //     256 random ones) -- the row id of every entry is stored explicitly (4 B/nnz: 14 B/nnz streamed);

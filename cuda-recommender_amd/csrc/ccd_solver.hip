@@ -570,12 +570,20 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
     const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
     auto options = [&](uint32_t nseg, uint32_t G, uint32_t elem_bytes) {
         if (!scatter) return choose_layout(*p, nseg, nnz_, G, elem_bytes, need_plain);
-        FlatLayoutOptions o;  // scatter: 24 B of LDS per local index (operand pair + two 64-bit accumulators)
+        // scatter: 24 B of LDS per local index (operand pair + two 64-bit accumulators) and the whole 160 KB of a CU
+        // for one workgroup: 6816 + 1 padding slot = 163 608 B.  Fewer, larger panels = fewer re-reads of the
+        // streamed operand, which is what bounds the pass (6144 -> 6816: 10 % fewer line fills).
+        constexpr uint32_t kScatterPanel = 6816;
+        FlatLayoutOptions o;
         o.scatter = true; o.lds = true; o.spans_per_wg = 16;
         o.scatter_ids32 = p->kernel_variant == 3;
-        o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : 6144u, std::max<uint32_t>(G, 1u));
-        // spans of 18 tiles when the matrix is large: a workgroup then flushes its 96 KB slab once per 74 k entries
-        o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : (nnz_ >= (32u << 20) ? 18u : 0u);
+        o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : kScatterPanel, std::max<uint32_t>(G, 1u));
+        // spans of 14 tiles when the matrix is large: a workgroup then flushes its 107 KB slab once per 57 k entries.
+        // Measured on the config-5 shard (tools/sweep_shard.sh, profiles/r02_sweep_shard.txt): 8 ... 32 tiles give
+        // 444-713 / 470-656 us per pass with no monotone trend (padding of every panel to whole chunks, slab traffic
+        // and address aliasing between the 16 spans of a workgroup pull in different directions); 14 is the best for
+        // both copies together.
+        o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : (nnz_ >= (32u << 20) ? 14u : 0u);
         return o;
     };
     scatter_ = scatter;

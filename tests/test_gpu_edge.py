@@ -119,7 +119,7 @@ def test_hyper_sparse_shard_layouts(mfx, orc):
     s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2))
     info = s.layout_info()
     s.close()
-    assert info["csc"]["kind"] == "scatter" and info["csr"]["kind"] == "scatter" and info["csc"]["panel_rows"] == 6144, info
+    assert info["csc"]["kind"] == "scatter" and info["csr"]["kind"] == "scatter" and info["csc"]["panel_rows"] == 6816, info
     s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2, layout_build=1))
     info = s.layout_info()
     s.close()
