@@ -161,6 +161,25 @@ struct FlatArgs {
     float2* part;   // [nne] (g, h) of every non-empty virtual segment, written by the span holding its head
     float2* carry;  // [nspans] (g, h) of a span's leading run that continues an earlier span's segment
     int add;
+    // ---- fused finalize (k_flat<..., FUSE = true>): the workgroup whose arrival completes a group of segments
+    // turns that group's partial sums into the new factor entries inside the pass (see fused_finalize below)
+    const uint32_t* wg_order;   // [workgroups] dispatch slot -> chunk, ascending first segment
+    const uint32_t* wg_g0;      // [workgroups] first / last segment group a chunk contributes to (g0 > g1: none)
+    const uint32_t* wg_g1;
+    const uint32_t* expected;   // [groups] chunks contributing to a group
+    uint32_t* arrived;          // [groups] zero between launches: the completing workgroup resets its word
+    const uint32_t* orphans;    // [norphans] groups nobody contributes to (all segments empty): slot 0 finalizes them
+    uint32_t norphans, ngroups, panel_lanes;
+    // what k_finalize takes
+    uint32_t nseg, npanels;
+    const uint32_t* ptr_v;
+    const uint32_t* rank_code;
+    const uint32_t* seg_cnt;
+    float lambda;
+    float* out_vec;
+    float2* pack2;
+    const float* next_vec;
+    float4* pack4;
 };
 
 template <int MODE> struct ModeTraits;
@@ -200,21 +219,45 @@ __device__ __forceinline__ void element_op(float v, const typename ModeTraits<MO
 
 // PSCHK: some workgroup touches more ranks than the LDS per-segment window holds, so fetches
 // must check the window and fall back to global memory (decided on the host from the layout).
-template <int MODE, bool LDS, int BLOCK, bool PSCHK>
+template <int BLOCK> __device__ void fused_finalize(const FlatArgs& a, uint32_t chunk, unsigned char* lds_raw);
+
+// agent-scope, write-through (sc1) 8-byte store / load of a partial sum: what another workgroup of the SAME launch
+// may read needs no release fence on this side and no acquire on the other (cdna_hip_programming.md, guideline 16)
+using gu64 = __attribute__((address_space(1))) unsigned long long;
+using gu32 = __attribute__((address_space(1))) uint32_t;
+template <bool FUSE>
+__device__ __forceinline__ void store_partial(float2* p, float g, float h) {
+    if constexpr (FUSE) {
+        const unsigned long long bits = (unsigned long long) __builtin_bit_cast(uint32_t, g) | ((unsigned long long) __builtin_bit_cast(uint32_t, h) << 32);
+        __hip_atomic_store((gu64*) p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *p = make_float2(g, h);
+    }
+}
+__device__ __forceinline__ float2 load_partial_sc1(const float2* p) {
+    const unsigned long long bits = __hip_atomic_load((gu64*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__builtin_bit_cast(float, (uint32_t) bits), __builtin_bit_cast(float, (uint32_t) (bits >> 32)));
+}
+
+template <int MODE, bool LDS, int BLOCK, bool PSCHK, bool FUSE = false>
 __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
+    static_assert(!FUSE || (LDS && ModeTraits<MODE>::kDot), "fused finalize: LDS-panel passes that produce sums");
     using TR = ModeTraits<MODE>;
+    // FUSE: dispatch slot -> chunk through wg_order (ascending first segment, so that the chunks of one segment
+    // group run at about the same time and groups complete all along the pass, not at its end)
+    const uint32_t chunk = FUSE ? a.wg_order[blockIdx.x] : blockIdx.x;
     using G = typename TR::G;
     using P = typename TR::P;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     G* __restrict__ slice = reinterpret_cast<G*>(lds_raw);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t span = __builtin_amdgcn_readfirstlane(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+    const uint32_t span = __builtin_amdgcn_readfirstlane(chunk * (BLOCK / 64) + (threadIdx.x >> 6));
     const G* __restrict__ gather = static_cast<const G*>(a.gather);
     const P* __restrict__ perseg = static_cast<const P*>(a.perseg);
     const uint32_t span_words = a.tiles_per_span * (kTileElems / 32);
     if constexpr (LDS) {
         // stage this workgroup's panel slice; slot panel_rows is the zero entry padding points at
-        const uint32_t panel = a.wg_panel[blockIdx.x];
+        const uint32_t panel = a.wg_panel[chunk];
         const uint32_t gbase = panel * a.panel_rows;
         const uint32_t cnt = a.gather_len - gbase < a.panel_rows ? a.gather_len - gbase : a.panel_rows;
         for (uint32_t i = threadIdx.x; i < cnt; i += BLOCK) slice[i] = gather[gbase + i];
@@ -225,7 +268,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     P* __restrict__ ps_lds = reinterpret_cast<P*>(lds_raw + (((size_t) a.panel_rows + 1) * sizeof(G) + 15) / 16 * 16);
     uint32_t win_base = 0;
     if constexpr (LDS && TR::kPerSeg) {
-        const uint32_t first = blockIdx.x * (BLOCK / 64);
+        const uint32_t first = chunk * (BLOCK / 64);
         const uint32_t rb0 = a.hpre[(size_t) first * span_words];
         win_base = rb0 > 0 ? rb0 - 1 : 0;
         const uint32_t win_end = a.hpre[(size_t) (first + BLOCK / 64) * span_words];  // heads before the next chunk
@@ -234,7 +277,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) ps_lds[j] = perseg[a.seg_of_rank[win_base + j]];
     }
     if constexpr (LDS) __syncthreads();
-    if (span >= a.nspans) return;
+    if constexpr (!FUSE) { if (span >= a.nspans) return; }  // (LDS panels: never true, every chunk holds BLOCK / 64 spans)
     auto fetch_ps = [&](uint32_t r) -> P {  // r: rank, always valid where this is called
         if constexpr (LDS) {
             const uint32_t rl = r - win_base;
@@ -260,9 +303,11 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         const uint32_t live = (uint32_t) ((left + kTileElems - 1) / kTileElems);
         if (live < ntiles) ntiles = live;
     }
-    if (ntiles == 0) {  // nothing stored here (plain layout, nnz == 0): still own the carry slot
-        if (TR::kDot && lane == 0) a.carry[span] = make_float2(0.f, 0.f);
-        return;
+    if constexpr (!LDS) {
+        if (ntiles == 0) {  // nothing stored here (plain layout, nnz == 0): still own the carry slot
+            if (TR::kDot && lane == 0) a.carry[span] = make_float2(0.f, 0.f);
+            return;
+        }
     }
     IdxVec id_n = __builtin_nontemporal_load(idx4);
     f32x4 v_n = __builtin_nontemporal_load(val4);
@@ -356,7 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                         if (!seen) {
                             fg = ag; fh = ah; seen = true;
                         } else {  // head..head inside one lane: started in this span by construction
-                            a.part[close1 - 1] = make_float2(ag, ah);
+                            store_partial<FUSE>(a.part + (close1 - 1), ag, ah);
                         }
                         ++close1;
                         ag = 0.f; ah = 0.f;
@@ -376,9 +421,9 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
                 if (seen) {  // this lane's first head closes the segment of rank r1 - 1
                     const float tg = eg + fg, th = eh + fh;
                     if (r1 > rank_base) {  // it started inside this span: we own its slot
-                        a.part[r1 - 1] = make_float2(tg, th);
+                        store_partial<FUSE>(a.part + (r1 - 1), tg, th);
                     } else {  // it started in an earlier span: this is the span's head carry
-                        a.carry[span] = make_float2(tg, th);
+                        store_partial<FUSE>(a.carry + span, tg, th);
                     }
                 }
                 // new open segment: everything after the tile's last head
@@ -405,26 +450,35 @@ __builtin_nontemporal_store(f32x4{vo[0], vo[1], vo[2], vo[3]}, val4 + tile * 64)
         const float tg = open_spread ? wave_sum(og) : og, th = open_spread ? wave_sum(oh) : oh;
         if (lane == 0) {
             if (cur1 > rank_base) {  // the open segment's head lies in this span: we own its slot
-                a.part[cur1 - 1] = make_float2(tg, th);
+                store_partial<FUSE>(a.part + (cur1 - 1), tg, th);
             } else {  // the whole span is interior to one segment
-                a.carry[span] = make_float2(tg, th);
+                store_partial<FUSE>(a.carry + span, tg, th);
             }
         }
     }
+    if constexpr (FUSE) fused_finalize<BLOCK>(a, chunk, lds_raw);
 }
 
 
-// Adds, in span order, the carries that belong to the stored range [lo, hi).
+// Adds, in span order, the carries that belong to the stored range [lo, hi).  SC1: the partials were written by
+// other workgroups of the SAME launch (fused finalize) and are read past the caches.
+template <bool SC1>
+__device__ __forceinline__ float2 load_partial(const float2* p) {
+    if constexpr (SC1) return load_partial_sc1(p);
+    else return *p;
+}
+template <bool SC1 = false>
 __device__ __forceinline__ void add_carries(uint32_t lo, uint32_t hi, uint32_t span_len, const float2* __restrict__ carry,
                                             float& g, float& h) {
     uint32_t s = lo / span_len + 1;
     const uint32_t s_end = (hi - 1) / span_len;  // inclusive
     for (; s + 3 <= s_end; s += 4) {  // 4 independent loads in flight, sequential adds
-        const float2 c0 = carry[s], c1 = carry[s + 1], c2 = carry[s + 2], c3 = carry[s + 3];
+        const float2 c0 = load_partial<SC1>(carry + s), c1 = load_partial<SC1>(carry + s + 1), c2 = load_partial<SC1>(carry + s + 2),
+                     c3 = load_partial<SC1>(carry + s + 3);
         g += c0.x; g += c1.x; g += c2.x; g += c3.x;
         h += c0.y; h += c1.y; h += c2.y; h += c3.y;
     }
-    for (; s <= s_end; ++s) { const float2 c = carry[s]; g += c.x; h += c.y; }
+    for (; s <= s_end; ++s) { const float2 c = load_partial<SC1>(carry + s); g += c.x; h += c.y; }
 }
 
 struct GatherPartsArgs {
@@ -440,6 +494,7 @@ constexpr uint32_t kNoRank = 0xFFFFFFFFu, kCarryBit = 0x80000000u;
 // A lookup is rank -> part (two dependent loads; the carry bit says whether the segment runs into
 // later spans -- rare -- and only then are its pointers read), issued for kBatch panels at a time.
 // The additions stay in panel order.
+template <bool SC1 = false>
 __device__ __forceinline__ void segment_sums(const GatherPartsArgs& a, uint32_t c, uint32_t p0, uint32_t stride,
                                              float& g, float& h) {
     constexpr int kBatch = 5;
@@ -454,13 +509,13 @@ __device__ __forceinline__ void segment_sums(const GatherPartsArgs& a, uint32_t 
         }
         float2 pp[kBatch];
 #pragma unroll
-        for (int q = 0; q < kBatch; ++q) pp[q] = r[q] != kNoRank ? a.part[r[q] & ~kCarryBit] : make_float2(0.f, 0.f);
+        for (int q = 0; q < kBatch; ++q) pp[q] = r[q] != kNoRank ? load_partial<SC1>(a.part + (r[q] & ~kCarryBit)) : make_float2(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < kBatch; ++q) {
             if (r[q] != kNoRank) {
                 if (r[q] & kCarryBit) {
                     const size_t v = (size_t) (pb + q * stride) * a.nseg + c;
-                    add_carries(a.ptr_v[v], a.ptr_v[v + 1], a.span_len, a.carry, pp[q].x, pp[q].y);
+                    add_carries<SC1>(a.ptr_v[v], a.ptr_v[v + 1], a.span_len, a.carry, pp[q].x, pp[q].y);
                 }
                 g += pp[q].x;
                 h += pp[q].y;
@@ -557,6 +612,92 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused finalize (verdict r1, item 8) -- OPT-IN (MFX_FUSE_FINALIZE=1), because it measured slower.
+// k_finalize is two dependent HBM round trips behind a kernel boundary: 14-16 us, twice per rank, 8.6 % of
+// the Netflix-shape step.  Fused: segments are cut into groups of GS = BLOCK / panel_lanes; the layout
+// knows how many chunks contribute to a group (`expected`); a workgroup that has finished its chunk adds
+// 1 to the counter of every group it contributes to, and the workgroup whose add completes a group
+// finalizes it on the spot -- same lookups, same panel-lane split, same order of additions as
+// k_finalize, hence the same bits (tests: test_fused_finalize_equals_the_separate_kernel, and at the
+// Netflix shape test_fullsize_fused_finalize_is_bit_identical).
+// Visibility (cdna_hip_programming.md guideline 16, the fan-in row of MI355X_MICROARCH.md's table):
+// every partial is an sc1 (write-through) store; every wave drains its stores (vmcnt(0)) and the
+// workgroup meets before ONE agent-scope atomic add per group; the workgroup whose add returned
+// expected - 1 reads the partials with sc1 loads, after a barrier behind that add.  No wave waits for
+// another workgroup: nothing can hang.  The counters return to zero by themselves (the completing
+// workgroup resets its word; the next launch is a kernel boundary away).
+// Measured, Netflix shape, per launch (tools/exp_fuse.sh, profiles/r02_exp_fuse.txt):
+//   separate kernels                      CSC 184 + 17 us   CSR 189 + 17 us     25.7 ms per outer iteration
+//   fused, stored (panel-major) order     256               243                 31.8
+//   fused, dispatch by first segment      302               316                 39.1   (all 67 slices live at once)
+//   fused kernel, nobody completes + k_finalize   211 + 17  212 + 17            28.9   (plain stores: 207 / 207)
+// i.e. the arrival alone -- drain the stores, meet, one returning atomic -- costs ~20 us per pass: with 64 KB
+// of LDS per workgroup a CU holds two workgroups, each of the ~6 it runs in a row idles half the CU for
+// the 2-3 us of that round trip; and in stored order every group completes while the LAST panel is being
+// processed, so its ~45 workgroups do the whole finalize (6 serial group steps each).  A kernel boundary
+// is cheaper than both.
+template <int BLOCK>
+__device__ __forceinline__ void finalize_group(const FlatArgs& a, const GatherPartsArgs& ga, uint32_t group, float* sg, float* sh) {
+    const uint32_t PL = a.panel_lanes, SEGS = BLOCK / PL;
+    const uint32_t sl = threadIdx.x % SEGS, pl = threadIdx.x / SEGS;
+    const uint32_t c = group * SEGS + sl;
+    const bool owner = pl == 0 && c < a.nseg;
+    uint32_t cnt = 0;
+    float2 old = make_float2(0.f, 0.f);
+    float next = 0.f;
+    if (owner) {
+        cnt = a.seg_cnt[c];
+        if (a.pack2) { old = a.pack2[c]; next = a.next_vec[c]; }
+    }
+    float g = 0.f, h = 0.f;
+    if (c < a.nseg) segment_sums<true>(ga, c, pl, PL, g, h);
+    if (PL > 1) {
+        sg[threadIdx.x] = g;
+        sh[threadIdx.x] = h;
+        __syncthreads();
+        if (pl == 0)
+            for (uint32_t q = 1; q < PL; ++q) { g += sg[q * SEGS + sl]; h += sh[q * SEGS + sl]; }
+        __syncthreads();
+    }
+    if (!owner) return;
+    const float x = cnt ? g / add_rn(mul_rn(a.lambda, (float) cnt), h) : 0.f;
+    a.out_vec[c] = x;
+    if (a.pack2) {
+        if (a.pack4) a.pack4[c] = make_float4(old.x, old.y, x, 0.f);
+        a.pack2[c] = make_float2(x, a.next_vec == a.out_vec ? x : next);
+    }
+}
+
+template <int BLOCK>
+__device__ void fused_finalize(const FlatArgs& a, uint32_t chunk, unsigned char* lds_raw) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its partials have left the CU
+    __syncthreads();
+    float* sg = reinterpret_cast<float*>(lds_raw);     // the slice and the operand window are dead now
+    float* sh = sg + BLOCK;
+    uint32_t* todo = reinterpret_cast<uint32_t*>(sh + BLOCK);  // [0] = count, then the groups this workgroup completed
+    if (threadIdx.x == 0) todo[0] = 0;
+    __syncthreads();
+    const uint32_t g0 = a.wg_g0[chunk], g1 = a.wg_g1[chunk];
+    if (g0 <= g1) {
+        for (uint32_t g = g0 + threadIdx.x; g <= g1; g += BLOCK) {
+            const uint32_t before = __hip_atomic_fetch_add((gu32*) (a.arrived + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1 == a.expected[g]) {
+                __hip_atomic_store((gu32*) (a.arrived + g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                todo[1 + atomicAdd(&todo[0], 1u)] = g;
+            }
+        }
+    }
+    __syncthreads();  // behind the adds: the sc1 loads below come after the add that completed their group
+    GatherPartsArgs ga;
+    ga.nseg = a.nseg; ga.npanels = a.npanels; ga.span_len = a.tiles_per_span * kTileElems; ga.ptr_v = a.ptr_v;
+    ga.rank_code = a.rank_code; ga.part = a.part; ga.carry = a.carry;
+    const uint32_t ntodo = todo[0];
+    for (uint32_t i = 0; i < ntodo; ++i) finalize_group<BLOCK>(a, ga, todo[1 + i], sg, sh);
+    if (blockIdx.x == 0)
+        for (uint32_t i = 0; i < a.norphans; ++i) finalize_group<BLOCK>(a, ga, a.orphans[i], sg, sh);
+}
+
 __global__ __launch_bounds__(kBlock) void k_unpermute(uint64_t n, const uint32_t* __restrict__ perm,
                                                       const float* __restrict__ val, float* __restrict__ out) {
     const uint64_t e = (uint64_t) blockIdx.x * kBlock + threadIdx.x;
@@ -645,6 +786,32 @@ __global__ __launch_bounds__(kBlock) void k_check_range(uint64_t n, const uint32
     if (bad != ~0ull) atomicMin(first_bad, bad);
 }
 
+// First / last segment among the REAL entries of every workgroup chunk (the fused finalize's group tables are
+// derived from these on the host): the virtual segment holding stored position q is the last v with
+// ptr_v[v] <= q (empty ones share their successor's start, so that one is never empty).
+__global__ __launch_bounds__(kBlock) void k_chunk_seg_range(uint32_t nchunks, uint64_t chunk_len, const uint32_t* __restrict__ ptr_v,
+                                                             size_t nv, uint32_t nseg, const uint32_t* __restrict__ wg_panel,
+                                                             const uint32_t* __restrict__ panel_end, uint32_t* __restrict__ seg_first,
+                                                             uint32_t* __restrict__ seg_last) {
+    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
+    if (w >= nchunks) return;
+    const uint64_t lo = (uint64_t) w * chunk_len;
+    uint64_t hi = lo + chunk_len;
+    const uint32_t pe = panel_end[wg_panel[w]];
+    if (hi > pe) hi = pe;
+    if (hi <= lo) { seg_first[w] = 0xFFFFFFFFu; seg_last[w] = 0; return; }
+    auto holder = [&](uint32_t q) {  // last v in [0, nv) with ptr_v[v] <= q
+        size_t a = 0, b = nv;        // invariant: ptr_v[a] <= q (ptr_v[0] = 0), answer in [a, b)
+        while (b - a > 1) {
+            const size_t mid = a + (b - a) / 2;
+            if (ptr_v[mid] <= q) a = mid; else b = mid;
+        }
+        return (uint32_t) (a % nseg);
+    };
+    seg_first[w] = holder((uint32_t) lo);
+    seg_last[w] = holder((uint32_t) (hi - 1));
+}
+
 uint32_t seg_grid(uint32_t nseg) {
     // wave-per-segment kernels grid-stride; 8 blocks per CU is plenty
     const uint32_t want = (nseg + (kBlock / 64) - 1) / (kBlock / 64);
@@ -674,13 +841,13 @@ int ensure_dynamic_lds(const void* kernel, LdsAttrCache& c, size_t lds_bytes) {
 }
 }  // namespace
 
-template <int MODE, bool LDS, int BLOCK, bool PSCHK>
+template <int MODE, bool LDS, int BLOCK, bool PSCHK, bool FUSE = false>
 int launch_flat_t(const FlatArgs& a, uint32_t grid, size_t lds_bytes, hipStream_t st) {
     if (lds_bytes > 48 * 1024) {
         static LdsAttrCache cache;  // per instantiation
-        MFX_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_flat<MODE, LDS, BLOCK, PSCHK>), cache, lds_bytes));
+        MFX_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(k_flat<MODE, LDS, BLOCK, PSCHK, FUSE>), cache, lds_bytes));
     }
-    hipLaunchKernelGGL((k_flat<MODE, LDS, BLOCK, PSCHK>), dim3(grid), dim3(BLOCK), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_flat<MODE, LDS, BLOCK, PSCHK, FUSE>), dim3(grid), dim3(BLOCK), lds_bytes, st, a);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
 }
@@ -708,9 +875,8 @@ int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
     }
 }
 
-int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, int add,
-                hipStream_t st) {
-    FlatArgs a;
+static FlatArgs flat_args_of(const SegStreamDev& s, const void* gather, const void* perseg, int add) {
+    FlatArgs a = {};
     a.idx = s.lds_panels ? static_cast<const void*>(s.idx16) : static_cast<const void*>(s.idx);
     a.val = s.val; a.flags32 = s.flags32; a.hpre = s.hpre; a.seg_of_rank = s.seg_of_rank;
     a.wg_panel = s.wg_panel; a.nspans = s.nspans;
@@ -718,6 +884,39 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
     // cache panels: padding sits at every panel's end and gathers a zero, so no tile is masked by position
     a.nnz = (s.panel_rows && !s.lds_panels) ? s.padded_nnz : s.nnz; a.gather = gather; a.perseg = perseg; a.part = s.part;
     a.carry = s.carry; a.add = add;
+    return a;
+}
+
+static int panel_lanes(const SegStreamDev& s);
+uint32_t fused_group_size(uint32_t npanels) { return 1024u / (npanels >= 8 ? 16u : npanels >= 2 ? 4u : 1u); }
+
+template <int MODE>
+int launch_flat_fused_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
+    using G = typename ModeTraits<MODE>::G;
+    size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(G) + 15) / 16 * 16 + (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
+    const size_t epilogue = 2 * 1024 * sizeof(float) + ((size_t) s.fz_max_chunk_groups + 2) * sizeof(uint32_t);
+    if (lds_bytes < epilogue) lds_bytes = epilogue;
+    const uint32_t grid = s.nspans / s.spans_per_wg;
+    if (s.max_wg_ranks > kPerSegLdsCap) return launch_flat_t<MODE, true, 1024, true, true>(a, grid, lds_bytes, st);
+    return launch_flat_t<MODE, true, 1024, false, true>(a, grid, lds_bytes, st);
+}
+
+int launch_flat_fused(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, const FinalizeArgs& f, hipStream_t st) {
+    MFX_REQUIRE(s.lds_panels && s.spans_per_wg == 16 && s.fz_order && s.fz_g0 && s.fz_g1 && s.fz_expected && s.fz_arrived,
+                "launch_flat_fused: the layout carries no fused-finalize tables");
+    MFX_REQUIRE(!f.gh_dense && !f.cnt_override && !f.pack4_as3, "launch_flat_fused: dense / overridden finalize inputs are not fused");
+    MFX_REQUIRE(mode == FM_FCSC || mode == FM_FCSR, "launch_flat_fused: bad mode %d", (int) mode);
+    FlatArgs a = flat_args_of(s, gather, perseg, 0);
+    a.wg_order = s.fz_order; a.wg_g0 = s.fz_g0; a.wg_g1 = s.fz_g1; a.expected = s.fz_expected; a.arrived = s.fz_arrived;
+    a.orphans = s.fz_orphans; a.norphans = s.fz_norphans; a.ngroups = s.fz_ngroups; a.panel_lanes = (uint32_t) panel_lanes(s);
+    a.nseg = s.nseg; a.npanels = s.npanels; a.ptr_v = s.ptr_v; a.rank_code = s.rank_code; a.seg_cnt = s.seg_cnt;
+    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
+    return mode == FM_FCSC ? launch_flat_fused_mode<FM_FCSC>(s, a, st) : launch_flat_fused_mode<FM_FCSR>(s, a, st);
+}
+
+int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, int add,
+                hipStream_t st) {
+    const FlatArgs a = flat_args_of(s, gather, perseg, add);
     switch (mode) {
         case FM_SWEEP: return launch_flat_mode<FM_SWEEP>(s, a, st);
         case FM_RESID: return launch_flat_mode<FM_RESID>(s, a, st);
@@ -725,6 +924,16 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
         case FM_FCSR: return launch_flat_mode<FM_FCSR>(s, a, st);
         default: return fail(MFX_ERR_INVALID, "launch_flat: bad mode %d", (int) mode);
     }
+}
+
+int launch_chunk_seg_range(const SegStreamDev& s, const uint32_t* panel_end, uint32_t* seg_first, uint32_t* seg_last, hipStream_t st) {
+    const uint32_t nchunks = s.nspans / s.spans_per_wg;
+    if (nchunks == 0) return MFX_OK;
+    hipLaunchKernelGGL(k_chunk_seg_range, dim3((nchunks + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nchunks,
+                       (uint64_t) s.tiles_per_span * kTileElems * s.spans_per_wg, s.ptr_v, (size_t) s.npanels * s.nseg, s.nseg, s.wg_panel,
+                       panel_end, seg_first, seg_last);
+    MFX_LAUNCH_CHECK();
+    return MFX_OK;
 }
 
 int check_index_range(const uint32_t* d_idx, uint64_t n, uint32_t bound, const char* what, hipStream_t st) {
@@ -769,7 +978,7 @@ static GatherPartsArgs parts_of(const SegStreamDev& s) {
     return g;
 }
 
-static int panel_lanes(const SegStreamDev& s) { return s.npanels >= 8 ? 16 : s.npanels >= 2 ? 4 : 1; }
+static int panel_lanes(const SegStreamDev& s) { return s.npanels >= 8 ? 16 : s.npanels >= 2 ? 4 : 1; }  // = 1024 / fused_group_size(npanels)
 
 int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st) {
     if (s.nseg == 0) return MFX_OK;

@@ -48,6 +48,14 @@ struct SegStreamDev {
     const uint32_t* tile_base = nullptr;       // [padded nnz / 256] segment of a tile's first sorted entry
     unsigned long long* wgacc = nullptr;       // [workgroups][2 * panel_rows] fixed-point (g, h) slabs
     const uint32_t* wg_lo = nullptr;           // [npanels + 1] first workgroup of every panel
+    // fused finalize (LDS panels, 16-span workgroups): see fused_finalize in ccd_kernels.hip; nullptr = not available
+    const uint32_t* fz_order = nullptr;        // [workgroups] dispatch slot -> chunk
+    const uint32_t* fz_g0 = nullptr;           // [workgroups] first / last segment group of a chunk
+    const uint32_t* fz_g1 = nullptr;
+    const uint32_t* fz_expected = nullptr;     // [groups]
+    uint32_t* fz_arrived = nullptr;            // [groups], zero between launches
+    const uint32_t* fz_orphans = nullptr;      // [fz_norphans]
+    uint32_t fz_norphans = 0, fz_ngroups = 0, fz_max_chunk_groups = 0;
     // reduction scratch written by the flat kernels
     float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
     float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run
@@ -102,6 +110,13 @@ struct FinalizeArgs {
     bool pack4_as3 = false;             // ... stored as 12-byte triples in the same buffer (scatter u-pass: the streamed operand's line fills are what bounds it)
 };
 int launch_finalize(const SegStreamDev& s, const FinalizeArgs& a, hipStream_t st);
+// segments per group of the fused finalize = 1024 / panel lanes of the finalize (a function of the panel count)
+uint32_t fused_group_size(uint32_t npanels);
+// FM_FCSC / FM_FCSR pass + the finalize of its sums inside the same launch (s.fz_* must be set; f.gh_dense and
+// f.cnt_override are not supported: sharded column sums go through the all-reduce and the separate kernel)
+int launch_flat_fused(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, const FinalizeArgs& f, hipStream_t st);
+// first / last segment of every workgroup chunk's real entries (0xFFFFFFFF / 0 for a chunk of padding only)
+int launch_chunk_seg_range(const SegStreamDev& s, const uint32_t* panel_end, uint32_t* seg_first, uint32_t* seg_last, hipStream_t st);
 
 // out[perm[e]] = val[e] for every stored, non-padding element: residual back in input order.
 int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st);

@@ -11,6 +11,7 @@
 #include "ccd_solver.hpp"
 #include "layout_kernels.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -45,12 +46,64 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     if (build_mode != 1) {
         bool done = false;
         MFX_TRY(build_device(nseg, nnz, G, ptr, idx, val, space, opt, st, &done));
-        if (done) { built_on_device_ = true; return MFX_OK; }
+        if (done) { built_on_device_ = true; return build_fuse_tables(st); }
         MFX_REQUIRE(build_mode != 2, "layout_build = 2: the pattern is not grouped (some segment visits a panel more than "
                                      "once; sort the indices inside every row / column) -- the device builder cannot take it");
     }
     MFX_REQUIRE(!opt.scatter, "the scatter layout is built by the device pipeline only (pattern not grouped, or layout_build = 1)");
-    return build_host(nseg, nnz, G, ptr, idx, val, space, opt, st);
+    MFX_TRY(build_host(nseg, nnz, G, ptr, idx, val, space, opt, st));
+    return build_fuse_tables(st);
+}
+
+// Fused finalize: which segment groups each workgroup chunk contributes to, how many chunks a group waits for, and
+// the dispatch order (ascending first segment).  One small kernel finds every chunk's first / last segment; the
+// rest is host arithmetic over a few thousand chunks.
+int SegStreamStore::build_fuse_tables(hipStream_t st) {
+    if (!view.lds_panels || view.spans_per_wg != 16 || view.scatter || view.nseg == 0 || view.nspans == 0) return MFX_OK;
+    const uint32_t nchunks = view.nspans / view.spans_per_wg;
+    if (panel_end_dev_.size() == 0) {
+        const std::vector<uint32_t>& pe = built_on_device_ ? panel_end_host_ : layout_.panel_real_end;
+        if (pe.size() != view.npanels) return MFX_OK;  // no panel ends at hand: the separate finalize kernel stays
+        MFX_TRY(panel_end_dev_.alloc(pe.size()));
+        MFX_TRY(panel_end_dev_.upload(pe.data(), pe.size(), MFX_HOST, st));
+    }
+    DevBuf<uint32_t> d_first, d_last;
+    MFX_TRY(d_first.alloc(nchunks)); MFX_TRY(d_last.alloc(nchunks));
+    MFX_TRY(launch_chunk_seg_range(view, panel_end_dev_.get(), d_first.get(), d_last.get(), st));
+    std::vector<uint32_t> first(nchunks), last(nchunks);
+    MFX_HIP(hipMemcpyAsync(first.data(), d_first.get(), sizeof(uint32_t) * nchunks, hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipMemcpyAsync(last.data(), d_last.get(), sizeof(uint32_t) * nchunks, hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    const uint32_t gs = fused_group_size(view.npanels), ngroups = (view.nseg + gs - 1) / gs;
+    std::vector<uint32_t> g0(nchunks), g1(nchunks), expected(ngroups, 0u), order(nchunks), orphans;
+    uint32_t max_groups = 0;
+    for (uint32_t w = 0; w < nchunks; ++w) {
+        if (first[w] == 0xFFFFFFFFu) { g0[w] = 1; g1[w] = 0; continue; }  // padding only: contributes nowhere
+        MFX_REQUIRE(first[w] <= last[w] && last[w] < view.nseg, "fused finalize: chunk %u covers segments %u..%u", w, first[w], last[w]);
+        g0[w] = first[w] / gs; g1[w] = last[w] / gs;
+        for (uint32_t g = g0[w]; g <= g1[w]; ++g) ++expected[g];
+        max_groups = std::max(max_groups, g1[w] - g0[w] + 1);
+    }
+    for (uint32_t g = 0; g < ngroups; ++g) if (expected[g] == 0) orphans.push_back(g);
+    for (uint32_t w = 0; w < nchunks; ++w) order[w] = w;
+    // MFX_FUSE_FINALIZE=2: dispatch in ascending order of the first segment, so that a group's chunks run at about
+    // the same time and groups complete all along the pass (1: stored, panel-major order -- groups complete while the
+    // last panel is processed).  Measured slower still: every panel's slice is then live at once.
+    const char* fz_env = std::getenv("MFX_FUSE_FINALIZE");
+    if (fz_env && std::atoi(fz_env) == 2)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });  // padding-only chunks last
+    MFX_TRY(fz_order_.alloc(nchunks)); MFX_TRY(fz_order_.upload(order.data(), nchunks, MFX_HOST, st));
+    MFX_TRY(fz_g0_.alloc(nchunks)); MFX_TRY(fz_g0_.upload(g0.data(), nchunks, MFX_HOST, st));
+    MFX_TRY(fz_g1_.alloc(nchunks)); MFX_TRY(fz_g1_.upload(g1.data(), nchunks, MFX_HOST, st));
+    MFX_TRY(fz_expected_.alloc(ngroups)); MFX_TRY(fz_expected_.upload(expected.data(), ngroups, MFX_HOST, st));
+    MFX_TRY(fz_arrived_.alloc_zero(ngroups, st));
+    MFX_TRY(fz_orphans_.alloc(orphans.empty() ? 1 : orphans.size()));
+    MFX_TRY(fz_orphans_.upload(orphans.data(), orphans.size(), MFX_HOST, st));
+    MFX_HIP(hipStreamSynchronize(st));  // the host vectors behind the uploads
+    view.fz_order = fz_order_.get(); view.fz_g0 = fz_g0_.get(); view.fz_g1 = fz_g1_.get(); view.fz_expected = fz_expected_.get();
+    view.fz_arrived = fz_arrived_.get(); view.fz_orphans = fz_orphans_.get(); view.fz_norphans = (uint32_t) orphans.size();
+    view.fz_ngroups = ngroups; view.fz_max_chunk_groups = max_groups;
+    return MFX_OK;
 }
 
 // Device pipeline (layout_kernels.hpp).  Host-resident inputs are uploaded as they are (12 B per
@@ -513,6 +566,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     for (hipEvent_t& e : ev_) MFX_HIP(hipEventCreate(&e));
     m_ = (uint32_t) R->rows; n_ = (uint32_t) R->cols; k_ = p->k; nnz_ = (uint64_t) R->nnz;
     prof_.enable(p->profile != 0 || p->schedule == 0);
+    if (const char* e = std::getenv("MFX_FUSE_FINALIZE")) fuse_finalize_ = std::atoi(e) != 0;  // opt-in: see fuse_finalize_
 
     // Layouts.  Hyper-sparse shapes (LDS-sized panels would leave < 8 entries per (panel, segment) pair on
     // either side, so that side would fall back to L2 "cache panels") take the scatter layout on BOTH sides
@@ -696,16 +750,27 @@ int CcdSolver::rank_fused(uint32_t t) {
     if (scatter_) return rank_fused_scatter(t);
     const uint32_t next = (t + 1) % k_;
     // invariant on entry: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old)
-    PROF(KernelProfiler::K_FCSC, launch_flat(FM_FCSC, csc_.view, packA_.get(), packB_.get(), 0, st_));
+    // With MFX_FUSE_FINALIZE=1 the finalize of each pass runs INSIDE the pass (fused_finalize, ccd_kernels.hip);
+    // the column side of a sharded solve keeps the separate kernel: its sums go through the all-reduce first.
+    // Off by default: bit-identical, but measured SLOWER than pass + k_finalize (see the comment there).
     FinalizeArgs fv;
     fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next);
     fv.pack4 = packC_.get();
-    MFX_TRY(finalize_cols(fv));
+    if (fuse_finalize_ && !comm_ && csc_.can_fuse_finalize()) {
+        PROF(KernelProfiler::K_FCSC, launch_flat_fused(FM_FCSC, csc_.view, packA_.get(), packB_.get(), fv, st_));
+    } else {
+        PROF(KernelProfiler::K_FCSC, launch_flat(FM_FCSC, csc_.view, packA_.get(), packB_.get(), 0, st_));
+        MFX_TRY(finalize_cols(fv));
+    }
     // per-row scalars of the CSR pass are exactly packA (u_prev_new, u_t_old), indexed by row
-    PROF(KernelProfiler::K_FCSR, launch_flat(FM_FCSR, csr_.view, packC_.get(), packA_.get(), 0, st_));
     FinalizeArgs fu;
     fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
-    PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, fu, st_));
+    if (fuse_finalize_ && csr_.can_fuse_finalize()) {
+        PROF(KernelProfiler::K_FCSR, launch_flat_fused(FM_FCSR, csr_.view, packC_.get(), packA_.get(), fu, st_));
+    } else {
+        PROF(KernelProfiler::K_FCSR, launch_flat(FM_FCSR, csr_.view, packC_.get(), packA_.get(), 0, st_));
+        PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, fu, st_));
+    }
 
     for (int it = 2; it <= p_.maxinneriter; ++it) {  // remaining inner iterations: read-only sweeps
         PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csc_.view, Wt(t), nullptr, 0, st_));

@@ -23,6 +23,7 @@ public:
     int build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx, const float* val,
               mfx_memspace space, const FlatLayoutOptions& opt, int build_mode, hipStream_t st);
     bool built_on_device() const { return built_on_device_; }
+    bool can_fuse_finalize() const { return view.fz_order != nullptr; }
     SegStreamDev view;
     const FlatLayoutHost& layout() const { return layout_; }
     // out[input position] = stored value, for every real entry (test / debug path: mfx_ccd_get_residual)
@@ -34,8 +35,11 @@ private:
     // *done = false (and MFX_OK) when the pattern is not grouped: nothing was built
     int build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_t* ptr, const uint32_t* idx, const float* val,
                      mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st, bool* done);
+    // group tables of the fused finalize (LDS panels with 16-span workgroups; ccd_kernels.hip, fused_finalize)
+    int build_fuse_tables(hipStream_t st);
     bool built_on_device_ = false;
     FlatLayoutHost layout_;
+    DevBuf<uint32_t> fz_order_, fz_g0_, fz_g1_, fz_expected_, fz_arrived_, fz_orphans_;
     DevBuf<uint32_t> ptr_, ptr_v_, seg_cnt_, idx_, seg_of_rank_, flags32_, hpre_, wg_panel_, perm_;
     DevBuf<float> val_;
     DevBuf<float2> part_, carry_;
@@ -100,6 +104,7 @@ private:
     CcdSolver() = default;
     int init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space,
              const mfx_shard* shard);
+    bool fuse_finalize_ = false;  // MFX_FUSE_FINALIZE=1 / 2: finalize inside the fused passes (bit-identical; measured slower)
     int rank_fused(uint32_t t);
     int rank_as_written(uint32_t t, bool add_back);
     int flush_pending();

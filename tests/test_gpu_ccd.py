@@ -395,3 +395,30 @@ def test_failing_shard_does_not_strand_the_others(mfx, medium):
     [x.join(timeout=120) for x in th]
     assert not any(x.is_alive() for x in th), res
     assert res[2] == "aborted" and all(isinstance(x, str) and x.startswith("error") and "aborted" in x for x in res[:2]), res
+
+
+@pytest.mark.parametrize("panel_rows,tiles,T", [(64, 0, 1), (97, 2, 1), (4096, 0, 2), (300, 4, 1)])
+def test_fused_finalize_equals_the_separate_kernel(mfx, medium, monkeypatch, panel_rows, tiles, T):
+    """Opt-in (MFX_FUSE_FINALIZE=1, =2 with the dispatch sorted by first segment; off by default because it measured
+    slower): the finalize of a fused pass runs inside the pass (the workgroup whose arrival completes a group of segments
+    computes g / (lambda |Omega| + h) for it, reading the other workgroups' partial sums past the caches):
+    same lookups and order of additions as k_finalize, so factors, RMSE trace and residuals are bit-identical to
+    a solve with MFX_FUSE_FINALIZE=0 -- on layouts with many panels and short spans (many chunks per group,
+    segments crossing chunks) and over several outer iterations (the arrival counters reset themselves)."""
+    d = medium
+    k, lam, t = 6, 0.05, 4
+    W0 = mfx.initial_col(k, d.rows)
+    outs = []
+    for fuse in ("1", "2", "0"):
+        monkeypatch.setenv("MFX_FUSE_FINALIZE", fuse)
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, T, 1, 1, tiles, panel_rows))
+        s.set_factors(W0.copy())
+        rep = s.iterate(t)
+        W, H = s.get_factors()
+        csc, csr = s.get_residual(d.nnz)
+        s.close()
+        outs.append((W, H, csc, csr, np.array([r.rmse for r in rep])))
+    for o in outs[:2]:
+        for a, b in zip(o[:4], outs[2][:4]):
+            assert np.array_equal(bits(a), bits(b))
+        assert np.array_equal(o[4], outs[2][4])

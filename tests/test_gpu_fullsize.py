@@ -329,3 +329,18 @@ def test_config5_shard_vs_oracle():
     scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
     assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale
     assert np.abs(csc - csc_ref).max() < 1e-3 and np.abs(csr - csr_ref).max() < 1e-3
+
+
+def test_fullsize_fused_finalize_is_bit_identical(big, monkeypatch):
+    """Opt-in path (MFX_FUSE_FINALIZE=1; off by default, it measured slower).  Netflix shape, k = 64, two outer iterations (256 fused passes, ~3 000 workgroups each, on all eight XCDs): the
+    in-pass finalize reads other workgroups' partial sums of the same launch; one stale read would change bits."""
+    mfx, torch, d = big
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MFX_FUSE_FINALIZE", fuse)
+        s, rep, W, H = _solve(mfx, d, 2)
+        s.close()
+        outs.append((W, H, np.array([r.rmse for r in rep])))
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    assert np.array_equal(outs[0][2], outs[1][2])
