@@ -255,7 +255,26 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     const G* __restrict__ gather = static_cast<const G*>(a.gather);
     const P* __restrict__ perseg = static_cast<const P*>(a.perseg);
     const uint32_t span_words = a.tiles_per_span * (kTileElems / 32);
+    const uint64_t start = (uint64_t) span * a.tiles_per_span * kTileElems;
+    // panel-local indices are 16-bit: 2 B/nnz instead of 4 (10 B/nnz per fused pass instead of 12)
+    using IdxVec = typename std::conditional<LDS, u16x4, u32x4>::type;
+    using IdxElem = typename std::conditional<LDS, uint16_t, uint32_t>::type;
+    const IdxVec* __restrict__ idx4 = reinterpret_cast<const IdxVec*>(static_cast<const IdxElem*>(a.idx) + start) + lane;
+    f32x4* __restrict__ val4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
+    // per-lane view of the head metadata: 8 lanes share one 32-element word
+    const uint32_t* __restrict__ flw = a.flags32 + (size_t) span * span_words + (lane >> 3);
+    const uint32_t* __restrict__ hpw = a.hpre + (size_t) span * span_words + (lane >> 3);
+    const uint32_t sh = (lane & 7) * 4;
+    IdxVec id_n;
+    f32x4 v_n;
+    uint32_t fl_n, hp_n, hp_nn;
     if constexpr (LDS) {
+        // The first tile's streams go out BEFORE the slice is staged: a CU holds two of these workgroups, and while
+        // one of them stages (two to three dependent round trips before its barrier) half the CU would otherwise
+        // have nothing in flight.  (LDS panels: every chunk holds BLOCK / 64 whole spans, so the span exists.)
+        id_n = __builtin_nontemporal_load(idx4);
+        v_n = __builtin_nontemporal_load(val4);
+        fl_n = flw[0]; hp_n = hpw[0]; hp_nn = hpw[8];
         // stage this workgroup's panel slice; slot panel_rows is the zero entry padding points at
         const uint32_t panel = a.wg_panel[chunk];
         const uint32_t gbase = panel * a.panel_rows;
@@ -286,32 +305,19 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         }
         return perseg[a.seg_of_rank[r]];
     };
-    const uint64_t start = (uint64_t) span * a.tiles_per_span * kTileElems;
-
-    // panel-local indices are 16-bit: 2 B/nnz instead of 4 (10 B/nnz per fused pass instead of 12)
-    using IdxVec = typename std::conditional<LDS, u16x4, u32x4>::type;
-    using IdxElem = typename std::conditional<LDS, uint16_t, uint32_t>::type;
-    const IdxVec* __restrict__ idx4 = reinterpret_cast<const IdxVec*>(static_cast<const IdxElem*>(a.idx) + start) + lane;
-    f32x4* __restrict__ val4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
-    // per-lane view of the head metadata: 8 lanes share one 32-element word
-    const uint32_t* __restrict__ flw = a.flags32 + (size_t) span * span_words + (lane >> 3);
-    const uint32_t* __restrict__ hpw = a.hpre + (size_t) span * span_words + (lane >> 3);
-    const uint32_t sh = (lane & 7) * 4;
     uint32_t ntiles = a.tiles_per_span;
     if constexpr (!LDS) {  // plain layout: tiles that start at or beyond nnz hold only padding
         const uint64_t left = a.nnz > start ? a.nnz - start : 0;
         const uint32_t live = (uint32_t) ((left + kTileElems - 1) / kTileElems);
         if (live < ntiles) ntiles = live;
-    }
-    if constexpr (!LDS) {
         if (ntiles == 0) {  // nothing stored here (plain layout, nnz == 0): still own the carry slot
             if (TR::kDot && lane == 0) a.carry[span] = make_float2(0.f, 0.f);
             return;
         }
+        id_n = __builtin_nontemporal_load(idx4);
+        v_n = __builtin_nontemporal_load(val4);
+        fl_n = flw[0]; hp_n = hpw[0]; hp_nn = hpw[8];
     }
-    IdxVec id_n = __builtin_nontemporal_load(idx4);
-    f32x4 v_n = __builtin_nontemporal_load(val4);
-    uint32_t fl_n = flw[0], hp_n = hpw[0], hp_nn = hpw[8];
     const uint32_t rank_base = __builtin_amdgcn_readfirstlane(hp_n);  // heads before this span
     uint32_t cur1 = rank_base;  // (rank of the segment open at the current position) + 1, wave-uniform
     P pcur{};
