@@ -182,11 +182,18 @@ struct FlatArgs {
     float4* pack4;
 };
 
+// G: element of the gathered operand in global memory; S: the same inside the LDS slice (the fused CSR pass keeps
+// 12 of its 16 bytes: 4 panels instead of 5 at the Netflix shape, and 4 VGPRs fewer per tile); P: per-segment operand
+struct F3 { float x, y, z; };
+template <typename S, typename G> __device__ __forceinline__ S to_slice(const G& g) { return g; }
+template <> __device__ __forceinline__ F3 to_slice<F3, float4>(const float4& g) { return F3{g.x, g.y, g.z}; }
+template <typename G, typename S> __device__ __forceinline__ G from_slice(const S& s) { return s; }
+template <> __device__ __forceinline__ float4 from_slice<float4, F3>(const F3& s) { return make_float4(s.x, s.y, s.z, 0.f); }
 template <int MODE> struct ModeTraits;
-template <> struct ModeTraits<FM_SWEEP> { using G = float;  using P = float;  static constexpr bool kPerSeg = false, kWrite = false, kDot = true; };
-template <> struct ModeTraits<FM_RESID> { using G = float;  using P = float;  static constexpr bool kPerSeg = true,  kWrite = true,  kDot = false; };
-template <> struct ModeTraits<FM_FCSC>  { using G = float2; using P = float2; static constexpr bool kPerSeg = true,  kWrite = true,  kDot = true; };
-template <> struct ModeTraits<FM_FCSR>  { using G = float4; using P = float2; static constexpr bool kPerSeg = true,  kWrite = true,  kDot = true; };
+template <> struct ModeTraits<FM_SWEEP> { using G = float;  using S = float;  using P = float;  static constexpr bool kPerSeg = false, kWrite = false, kDot = true; };
+template <> struct ModeTraits<FM_RESID> { using G = float;  using S = float;  using P = float;  static constexpr bool kPerSeg = true,  kWrite = true,  kDot = false; };
+template <> struct ModeTraits<FM_FCSC>  { using G = float2; using S = float2; using P = float2; static constexpr bool kPerSeg = true,  kWrite = true,  kDot = true; };
+template <> struct ModeTraits<FM_FCSR>  { using G = float4; using S = F3;     using P = float2; static constexpr bool kPerSeg = true,  kWrite = true,  kDot = true; };
 
 __device__ __forceinline__ float zero_of(float) { return 0.f; }
 __device__ __forceinline__ float2 zero_of(float2) { return make_float2(0.f, 0.f); }
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     using G = typename TR::G;
     using P = typename TR::P;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    G* __restrict__ slice = reinterpret_cast<G*>(lds_raw);
+    using S = typename TR::S;
+    S* __restrict__ slice = reinterpret_cast<S*>(lds_raw);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t span = __builtin_amdgcn_readfirstlane(chunk * (BLOCK / 64) + (threadIdx.x >> 6));
     const G* __restrict__ gather = static_cast<const G*>(a.gather);
@@ -279,12 +287,12 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         const uint32_t panel = a.wg_panel[chunk];
         const uint32_t gbase = panel * a.panel_rows;
         const uint32_t cnt = a.gather_len - gbase < a.panel_rows ? a.gather_len - gbase : a.panel_rows;
-        for (uint32_t i = threadIdx.x; i < cnt; i += BLOCK) slice[i] = gather[gbase + i];
-        if (threadIdx.x == 0) slice[a.panel_rows] = zero_of(G{});
+        for (uint32_t i = threadIdx.x; i < cnt; i += BLOCK) slice[i] = to_slice<S, G>(gather[gbase + i]);
+        if (threadIdx.x == 0) slice[a.panel_rows] = S{};
     }
     // The workgroup touches a contiguous window of ranks; stage their per-segment operands next to
     // the slice so that segmented tiles read LDS instead of chasing seg_of_rank -> perseg through L2.
-    P* __restrict__ ps_lds = reinterpret_cast<P*>(lds_raw + (((size_t) a.panel_rows + 1) * sizeof(G) + 15) / 16 * 16);
+    P* __restrict__ ps_lds = reinterpret_cast<P*>(lds_raw + (((size_t) a.panel_rows + 1) * sizeof(S) + 15) / 16 * 16);
     uint32_t win_base = 0;
     if constexpr (LDS && TR::kPerSeg) {
         const uint32_t first = chunk * (BLOCK / 64);
@@ -354,7 +362,7 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         G ga[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if constexpr (LDS) ga[e] = slice[ids[e]];
+            if constexpr (LDS) ga[e] = from_slice<G, S>(slice[ids[e]]);
             else ga[e] = ids[e] < a.gather_len ? gather[ids[e]] : zero_of(G{});  // cache panels pad with index G
         }
         float vo[4], gc[4], hc[4];
@@ -867,10 +875,9 @@ int launch_flat_lds(const SegStreamDev& s, const FlatArgs& a, uint32_t grid, siz
 
 template <int MODE>
 int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
-    using G = typename ModeTraits<MODE>::G;
     if (!s.lds_panels)
         return launch_flat_t<MODE, false, kBlock, false>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), 0, st);
-    size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(G) + 15) / 16 * 16;
+    size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(typename ModeTraits<MODE>::S) + 15) / 16 * 16;
     if (ModeTraits<MODE>::kPerSeg) lds_bytes += (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
     const uint32_t grid = s.nspans / s.spans_per_wg;
     switch (s.spans_per_wg) {
@@ -898,8 +905,7 @@ uint32_t fused_group_size(uint32_t npanels) { return 1024u / (npanels >= 8 ? 16u
 
 template <int MODE>
 int launch_flat_fused_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
-    using G = typename ModeTraits<MODE>::G;
-    size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(G) + 15) / 16 * 16 + (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
+    size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(typename ModeTraits<MODE>::S) + 15) / 16 * 16 + (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
     const size_t epilogue = 2 * 1024 * sizeof(float) + ((size_t) s.fz_max_chunk_groups + 2) * sizeof(uint32_t);
     if (lds_bytes < epilogue) lds_bytes = epilogue;
     const uint32_t grid = s.nspans / s.spans_per_wg;

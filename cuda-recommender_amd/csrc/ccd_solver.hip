@@ -410,6 +410,9 @@ int SegStreamStore::unpermute(float* out, hipStream_t st) {
 
 // LDS panels pay off when the gathered vector is too big for L1 yet cutting it into LDS-sized
 // panels leaves virtual segments long enough to amortise the per-segment bookkeeping.
+// LDS bytes per gathered index of the CSR copy's slice: (v_prev_new, v_t_old, v_t_new) -- ccd_kernels.hip, ModeTraits<FM_FCSR>::S
+constexpr uint32_t kCsrSliceBytes = 12;
+
 FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz, uint32_t G, uint32_t elem_bytes,
                                 bool need_plain) {
     FlatLayoutOptions o;
@@ -440,7 +443,7 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
         // pair).  Cut at L2 granularity instead: 2 MB slices keep every gather an L2 hit (measured,
         // tools/ubench_gather.hip sweep: 100 M 8-byte gathers take 0.60 ms against a 2 MB table, 1.01 ms
         // against 8 MB), with whole segments of >= 8 entries per slice or not at all.
-        const uint32_t cpr = (2u << 20) / elem_bytes;
+        const uint32_t cpr = (2u << 20) / (elem_bytes == kCsrSliceBytes ? 16u : elem_bytes);  // cache panels gather the float4 itself
         if (cpr >= G) return o;
         const uint64_t cpanels = (G + cpr - 1) / cpr;
         if ((double) nnz / ((double) cpanels * (double) (nseg ? nseg : 1)) < 8.0) return o;
@@ -574,7 +577,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
     bool want_scatter = p->kernel_variant == 2 || p->kernel_variant == 3;  // 3: scatter with explicit 32-bit ids
     if (!want_scatter && !need_plain && p->panel_rows == 0 && p->layout_build != 1) {
-        const FlatLayoutOptions a = choose_layout(*p, m_, nnz_, n_, sizeof(float4), false), b = choose_layout(*p, n_, nnz_, m_, sizeof(float2), false);
+        const FlatLayoutOptions a = choose_layout(*p, m_, nnz_, n_, kCsrSliceBytes, false), b = choose_layout(*p, n_, nnz_, m_, sizeof(float2), false);
         want_scatter = (a.panel_rows && !a.lds) || (b.panel_rows && !b.lds);
     }
     int rc = build_stores(R, p, space, want_scatter);
@@ -650,7 +653,7 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
         try {
             rc_csr = use_device(device_);
             if (rc_csr == MFX_OK)
-                rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, options(m_, n_, sizeof(float4)),
+                rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, options(m_, n_, kCsrSliceBytes),
                                     scatter ? 2 : p->layout_build, st_);
         } catch (const std::exception& ex) {
             rc_csr = fail(MFX_ERR_ALLOC, "building the CSR copy failed: %s", ex.what());
