@@ -433,6 +433,8 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     // 64 KB of LDS per workgroup (two 1024-thread workgroups per CU): 8 KB for the staged per-segment
     // operands, 56 KB for the slice.  Measured on the Netflix shape (round-1 sweep with a temporary env knob): slices of
     // 40/48/56/64/72 KB give 30.1/29.9/28.0/29.1/28.4 ms per outer iteration.
+    // (round 2, 12-byte CSR slice entries, CSC / CSR pass per launch: 48 KB 199 / 230 us, 56 KB 183 / 191, 64 KB 187 / 231,
+    // 71 KB 187 / 192 -- profiles/r02_exp_slice.txt)
     constexpr uint32_t slice_kb = 56;
     uint32_t pr = p.panel_rows > 0 ? (uint32_t) p.panel_rows : (slice_kb * 1024u) / elem_bytes - 1;
     if (pr >= G) pr = G;  // the whole gathered vector fits: one panel
