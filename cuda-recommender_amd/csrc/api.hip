@@ -142,6 +142,16 @@ int mfx_ccd_set_profile(mfx_ccd_t s, int on) {
         return s->impl->set_profile(on != 0);
     });
 }
+int mfx_ccd_rank_trace(mfx_ccd_t s, int cap, double* rmse, double* seconds, int iters_cap, int32_t* ranks_done) {
+    int n = 0;
+    const int rc = guarded("mfx_ccd_rank_trace", [&]() -> int {
+        MFX_REQUIRE(s && s->impl, "null argument");
+        MFX_REQUIRE(cap >= 0 && iters_cap >= 0, "negative capacity");
+        n = s->impl->rank_trace(cap, rmse, seconds, iters_cap, ranks_done);
+        return MFX_OK;
+    });
+    return rc == MFX_OK ? n : rc;
+}
 int mfx_ccd_layout_info(mfx_ccd_t s, int side, int32_t out[4]) {
     return guarded("mfx_ccd_layout_info", [&]() -> int {
         MFX_REQUIRE(s && s->impl && out, "null argument");

@@ -581,6 +581,8 @@ struct FinKernelArgs {
     const float* next_vec;
     float4* pack4;
     bool pack4_as3;
+    bool nmf;
+    double* fundec_seg;
 };
 
 template <int PL>
@@ -610,7 +612,22 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
         return;
     }
     // reference: g / (lambda * |Omega| + sum u^2), 0 for an empty segment (src/CCD.cpp:6-16,112)
-    const float x = cnt ? g / add_rn(mul_rn(a.lambda, (float) cnt), h) : 0.f;
+    const float den = add_rn(mul_rn(a.lambda, (float) cnt), h);
+    float x = cnt ? g / den : 0.f;
+    if (a.nmf || a.fundec_seg) {  // opt-in extensions (LIBPMF meaning of -N / -e; see FinalizeArgs)
+        const float was = a.pack2 ? old.y : a.out_vec[c];
+        double fd = 0.0;
+        if (cnt) {
+            if (a.nmf && x < 0.f) {
+                x = 0.f;
+                fd = -2.0 * (double) g * (double) was + (double) den * (double) was * (double) was;
+            } else {
+                const double delta = (double) was - (double) x;
+                fd = (double) den * delta * delta;
+            }
+        }
+        if (a.fundec_seg) a.fundec_seg[c] = fd;
+    }
     a.out_vec[c] = x;
     if (a.pack2) {
         if (a.pack4) {
@@ -771,6 +788,51 @@ __global__ __launch_bounds__(kBlock) void k_test_sqerr(int64_t nnz, const uint32
         }
         const double err = pred - (double) val[q];
         acc += err * err;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+}
+
+// *out += sum of x[0..n), one wave, fixed order
+__global__ void k_sum_add(uint32_t n, const double* __restrict__ x, double* __restrict__ out) {
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) acc += x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (threadIdx.x == 0) *out += acc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_test_resid_init(int64_t nnz, const uint32_t* __restrict__ row, const uint32_t* __restrict__ col,
+                                                            const float* __restrict__ val, const float* __restrict__ W,
+                                                            const float* __restrict__ H, int64_t rows, int64_t cols, int64_t k,
+                                                            float* __restrict__ resid) {
+    for (int64_t q = (int64_t) blockIdx.x * kBlock + threadIdx.x; q < nnz; q += (int64_t) gridDim.x * kBlock) {
+        const int64_t i = row[q], j = col[q];
+        float r = val[q];
+        for (int64_t t = 0; t < k; ++t) r = sub_rn(r, mul_rn(W[t * rows + i], H[t * cols + j]));
+        resid[q] = r;
+    }
+}
+
+// calrmse_r1, src/tools.cpp:261-270: the test residual follows one rank's change; per-block sums of its squares
+__global__ __launch_bounds__(kBlock) void k_test_r1(int64_t nnz, const uint32_t* __restrict__ row, const uint32_t* __restrict__ col,
+                                                    float* __restrict__ resid, const float* __restrict__ Wt, const float* __restrict__ Ht,
+                                                    const float* __restrict__ oldWt, const float* __restrict__ oldHt,
+                                                    double* __restrict__ partials) {
+    __shared__ double red[kBlock / 64];
+    double acc = 0.0;
+    for (int64_t q = (int64_t) blockIdx.x * kBlock + threadIdx.x; q < nnz; q += (int64_t) gridDim.x * kBlock) {
+        const uint32_t i = row[q], j = col[q];
+        const float r = sub_rn(resid[q], sub_rn(mul_rn(Wt[i], Ht[j]), mul_rn(oldWt[i], oldHt[j])));
+        resid[q] = r;
+        acc += (double) mul_rn(r, r);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -1008,13 +1070,17 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
     if (s.nseg == 0) return MFX_OK;
     FinKernelArgs a;
     a.parts = parts_of(s); a.seg_cnt = s.seg_cnt; a.gh_dense = f.gh_dense; a.cnt_override = f.cnt_override;
-    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4; a.pack4_as3 = f.pack4_as3;
+    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4; a.pack4_as3 = f.pack4_as3; a.nmf = f.nmf; a.fundec_seg = f.fundec_seg;
     const int pl = f.gh_dense ? 1 : panel_lanes(s);
     const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
     if (pl == 16) hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, st, a);
     else if (pl == 4) hipLaunchKernelGGL(k_finalize<4>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_finalize<1>, grid, block, 0, st, a);
     MFX_LAUNCH_CHECK();
+    if (f.fundec_seg && f.fundec_sum) {
+        hipLaunchKernelGGL(k_sum_add, dim3(1), dim3(64), 0, st, s.nseg, f.fundec_seg, f.fundec_sum);
+        MFX_LAUNCH_CHECK();
+    }
     return MFX_OK;
 }
 
@@ -1048,6 +1114,24 @@ int launch_test_sqerr(int64_t nnz_test, const uint32_t* row, const uint32_t* col
                       double* block_partials, uint32_t nblocks, double* sum_out, hipStream_t st) {
     hipLaunchKernelGGL(k_test_sqerr, dim3(nblocks), dim3(kBlock), 0, st, nnz_test, row, col, val, W, H, rows,
                        cols, k, ifALS, block_partials);
+    MFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, nblocks, block_partials, sum_out);
+    MFX_LAUNCH_CHECK();
+    return MFX_OK;
+}
+
+int launch_test_resid_init(int64_t nnz_test, const uint32_t* row, const uint32_t* col, const float* val, const float* W, const float* H,
+                           int64_t rows, int64_t cols, int64_t k, float* resid, hipStream_t st) {
+    if (nnz_test <= 0) return MFX_OK;
+    const uint32_t grid = (uint32_t) std::min<int64_t>((nnz_test + kBlock - 1) / kBlock, 256 * 8);
+    hipLaunchKernelGGL(k_test_resid_init, dim3(grid), dim3(kBlock), 0, st, nnz_test, row, col, val, W, H, rows, cols, k, resid);
+    MFX_LAUNCH_CHECK();
+    return MFX_OK;
+}
+
+int launch_test_r1(int64_t nnz_test, const uint32_t* row, const uint32_t* col, float* resid, const float* Wt, const float* Ht,
+                   const float* oldWt, const float* oldHt, double* block_partials, uint32_t nblocks, double* sum_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_test_r1, dim3(nblocks), dim3(kBlock), 0, st, nnz_test, row, col, resid, Wt, Ht, oldWt, oldHt, block_partials);
     MFX_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, nblocks, block_partials, sum_out);
     MFX_LAUNCH_CHECK();

@@ -107,9 +107,19 @@ struct FinalizeArgs {
     float2* pack2 = nullptr;            // in: (prev_new, cur_old); out: (cur_new, next_old)
     const float* next_vec = nullptr;    // W[t+1] / H[t+1] slice (old values)
     float4* pack4 = nullptr;            // out: (prev_new, cur_old, cur_new, 0), may be nullptr
+    // Opt-in extensions (mfx_params.do_nmf / eps; the reference parses these flags and ignores them):
+    bool nmf = false;                   // clamp the new value at 0
+    double* fundec_seg = nullptr;       // [nseg] scratch: per-segment function decrease h (old - new)^2 (clamped: -2 g old + h old^2)
+    double* fundec_sum = nullptr;       // *fundec_sum += sum of fundec_seg, in a fixed order (set together with fundec_seg)
     bool pack4_as3 = false;             // ... stored as 12-byte triples in the same buffer (scatter u-pass: the streamed operand's line fills are what bounds it)
 };
 int launch_finalize(const SegStreamDev& s, const FinalizeArgs& a, hipStream_t st);
+// calrmse_r1 (src/tools.cpp:261-270): resid[q] -= Wt[row] * Ht[col] - oldWt[row] * oldHt[col]; *sum_out = sum resid^2
+// resid[q] = val[q] - sum_t W[t][row] * H[t][col] (fp32, rank order): where a rank trace starts from
+int launch_test_resid_init(int64_t nnz_test, const uint32_t* row, const uint32_t* col, const float* val, const float* W, const float* H,
+                           int64_t rows, int64_t cols, int64_t k, float* resid, hipStream_t st);
+int launch_test_r1(int64_t nnz_test, const uint32_t* row, const uint32_t* col, float* resid, const float* Wt, const float* Ht,
+                   const float* oldWt, const float* oldHt, double* block_partials, uint32_t nblocks, double* sum_out, hipStream_t st);
 // segments per group of the fused finalize = 1024 / panel lanes of the finalize (a function of the panel count)
 uint32_t fused_group_size(uint32_t npanels);
 // FM_FCSC / FM_FCSR pass + the finalize of its sums inside the same launch (s.fz_* must be set; f.gh_dense and

@@ -548,6 +548,8 @@ CcdSolver::~CcdSolver() {
     if (graph_) (void) hipGraphDestroy(graph_);
     for (hipEvent_t& e : ev_)
         if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t& e : ev_rank_)
+        if (e) (void) hipEventDestroy(e);
     if (st_) {
         (void) hipStreamSynchronize(st_);
         (void) hipStreamDestroy(st_);
@@ -618,6 +620,21 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         MFX_TRY(check_index_range(t_col_.get(), (uint64_t) nnz_test_, n_, "test-set column", st_));
     }
     MFX_TRY(rmse_partials_.alloc_zero(kRmseBlocks, st_));
+    // opt-in extensions
+    MFX_REQUIRE(p->eps >= 0.f && p->eps < 1.f, "eps must be in [0, 1)");
+    ext_on_ = p->do_nmf != 0 || p->eps > 0.f || p->rank_trace != 0;
+    if (p->eps > 0.f || p->rank_trace) MFX_REQUIRE(!comm_, "eps / rank_trace are not available in a sharded solve");
+    if (p->eps > 0.f) {
+        MFX_TRY(fundec_seg_.alloc_zero(std::max(m_, n_), st_));
+        MFX_TRY(fundec_sum_.alloc_zero(1, st_));
+    }
+    if (p->rank_trace) {
+        MFX_TRY(old_w_.alloc_zero(m_, st_));
+        MFX_TRY(old_h_.alloc_zero(n_, st_));
+        MFX_TRY(test_resid_.alloc_zero(nnz_test_ > 0 ? (size_t) nnz_test_ : 1, st_));
+        MFX_TRY(r1_sum_.alloc_zero(1, st_));
+        for (hipEvent_t& e : ev_rank_) MFX_HIP(hipEventCreate(&e));
+    }
     MFX_TRY(rmse_sum_.alloc_zero(1, st_));
     MFX_HIP(hipStreamSynchronize(st_));
     return MFX_OK;
@@ -689,6 +706,7 @@ int CcdSolver::set_factors(const float* W, const float* H, mfx_memspace space) {
     MFX_HIP(hipStreamSynchronize(st_));
     pending_sub_ = -1;
     factors_set_ = true;
+    test_resid_valid_ = false;  // rank_trace: the test residual is rebuilt from the new factors
     return MFX_OK;
 }
 
@@ -725,23 +743,101 @@ int CcdSolver::scatter_finalize(bool cols, const FinalizeArgs& base) {
     return MFX_OK;
 }
 
+FinalizeArgs CcdSolver::fin_base() const {
+    FinalizeArgs f;
+    f.lambda = p_.lambda;
+    f.nmf = p_.do_nmf != 0;
+    if (p_.eps > 0.f) { f.fundec_seg = fundec_seg_.get(); f.fundec_sum = fundec_sum_.get(); }
+    return f;
+}
+
+// eps > 0: the function decrease of the inner iteration that just ran (its v- and u-update added it up on the
+// device) against eps * the running maximum of this outer iteration -- LIBPMF 1.41's rule, as restated in
+// oracle/mf_oracle.cpp (orc_ccdr1_ext).  One host round trip per inner iteration: this mode is opt-in.
+int CcdSolver::inner_stop(uint32_t t, int it, bool* stop) {
+    *stop = false;
+    if (!(p_.eps > 0.f)) return MFX_OK;
+    double cur = 0.0;
+    MFX_HIP(hipMemcpyAsync(&cur, fundec_sum_.get(), sizeof(double), hipMemcpyDeviceToHost, st_));
+    MFX_HIP(hipMemsetAsync(fundec_sum_.get(), 0, sizeof(double), st_));
+    MFX_HIP(hipStreamSynchronize(st_));
+    if (cur < fundec_max_ * (double) p_.eps) {
+        if (it == 1) ++early_stop_;
+        *stop = true;
+        return MFX_OK;
+    }
+    if (!(cur_oiter_ == 1 && t == 0 && it == 1)) fundec_max_ = std::max(fundec_max_, cur);
+    return MFX_OK;
+}
+
+// rank_trace: calrmse_r1 (src/tools.cpp:261-270) after every rank, as the commented block src/CCD.cpp:141-148 would
+// print it under verbose && do_predict.  The test residual starts as the test values minus the model's prediction.
+int CcdSolver::trace_begin(uint32_t t) {
+    if (!test_resid_valid_ && nnz_test_ > 0) {
+        MFX_TRY(flush_pending());
+        MFX_TRY(launch_test_resid_init(nnz_test_, t_row_.get(), t_col_.get(), t_val_.get(), W_.get(), H_.get(), m_, n_, k_,
+                                       test_resid_.get(), st_));
+        test_resid_valid_ = true;
+    }
+    MFX_HIP(hipMemcpyAsync(old_w_.get(), Wt(t), sizeof(float) * m_, hipMemcpyDeviceToDevice, st_));
+    MFX_HIP(hipMemcpyAsync(old_h_.get(), Ht(t), sizeof(float) * n_, hipMemcpyDeviceToDevice, st_));
+    MFX_HIP(hipEventRecord(ev_rank_[0], st_));
+    return MFX_OK;
+}
+
+int CcdSolver::trace_end(uint32_t t) {
+    MFX_HIP(hipEventRecord(ev_rank_[1], st_));
+    double sum = 0.0;
+    if (nnz_test_ > 0) {
+        MFX_TRY(launch_test_r1(nnz_test_, t_row_.get(), t_col_.get(), test_resid_.get(), Wt(t), Ht(t), old_w_.get(), old_h_.get(),
+                               rmse_partials_.get(), kRmseBlocks, r1_sum_.get(), st_));
+        MFX_HIP(hipMemcpyAsync(&sum, r1_sum_.get(), sizeof(double), hipMemcpyDeviceToHost, st_));
+    }
+    MFX_HIP(hipStreamSynchronize(st_));
+    float ms = 0.f;
+    MFX_HIP(hipEventElapsedTime(&ms, ev_rank_[0], ev_rank_[1]));
+    const size_t slot = trace_done_.size() * k_ + t;
+    if (trace_rmse_.size() <= slot) { trace_rmse_.resize(slot + 1, std::nan("")); trace_secs_.resize(slot + 1, 0.0); }
+    trace_rmse_[slot] = nnz_test_ > 0 ? std::sqrt(sum / (double) nnz_test_) : 0.0;
+    trace_secs_[slot] = ms * 1e-3;
+    if (p_.verbose) {  // the line of the commented block src/CCD.cpp:141-148
+        printf("iter %d rank %d time %f rmse %f\n", (int) cur_oiter_, (int) t + 1, trace_secs_[slot], trace_rmse_[slot]);
+        fflush(stdout);
+    }
+    return MFX_OK;
+}
+
+int CcdSolver::rank_trace(int cap, double* rmse, double* seconds, int iters_cap, int32_t* ranks_done) const {
+    const size_t n = trace_done_.size() * k_;
+    for (size_t i = 0; i < n && (int) i < cap; ++i) {
+        if (rmse) rmse[i] = i < trace_rmse_.size() ? trace_rmse_[i] : std::nan("");
+        if (seconds) seconds[i] = i < trace_secs_.size() ? trace_secs_[i] : 0.0;
+    }
+    for (size_t i = 0; i < trace_done_.size() && (int) i < iters_cap; ++i)
+        if (ranks_done) ranks_done[i] = trace_done_[i];
+    return (int) trace_done_.size();
+}
+
 int CcdSolver::rank_fused_scatter(uint32_t t) {
     const uint32_t next = (t + 1) % k_;
     // same invariant as rank_fused: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old).
     // v-update: stream the ROW-major copy; columns are local (slice packB, accumulators), rows stream (packA)
     PROF(KernelProfiler::K_SCAT_V, launch_scatter(SM_V, csr_.view, packB_.get(), packA_.get(), 0, st_));
-    FinalizeArgs fv;
+    FinalizeArgs fv = fin_base();
     fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next); fv.pack4 = packC_.get();
     fv.pack4_as3 = true;  // 12-byte triples: a quarter fewer line fills of the streamed operand in the u-pass
     MFX_TRY(scatter_finalize(true, fv));
     // u-update: stream the COLUMN-major copy; rows are local (slice packA), columns stream (packC, triples)
     PROF(KernelProfiler::K_SCAT_U, launch_scatter(SM_U, csc_.view, packA_.get(), packC_.get(), 0, st_));
-    FinalizeArgs fu;
+    FinalizeArgs fu = fin_base();
     fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
     MFX_TRY(scatter_finalize(false, fu));
-    for (int it = 2; it <= p_.maxinneriter; ++it) {  // remaining inner iterations: read-only sweeps
+    bool stop = false;
+    MFX_TRY(inner_stop(t, 1, &stop));
+    for (int it = 2; it <= p_.maxinneriter && !stop; ++it) {  // remaining inner iterations: read-only sweeps
         MFX_TRY(sweep(csc_, Wt(t), Ht(t), true));
         MFX_TRY(sweep(csr_, Ht(t), Wt(t), false));
+        MFX_TRY(inner_stop(t, it, &stop));
     }
     if (p_.maxinneriter > 1) {
         PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(t), Wt(next), packA_.get(), st_));
@@ -758,32 +854,35 @@ int CcdSolver::rank_fused(uint32_t t) {
     // With MFX_FUSE_FINALIZE=1 the finalize of each pass runs INSIDE the pass (fused_finalize, ccd_kernels.hip);
     // the column side of a sharded solve keeps the separate kernel: its sums go through the all-reduce first.
     // Off by default: bit-identical, but measured SLOWER than pass + k_finalize (see the comment there).
-    FinalizeArgs fv;
+    FinalizeArgs fv = fin_base();
     fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next);
     fv.pack4 = packC_.get();
-    if (fuse_finalize_ && !comm_ && csc_.can_fuse_finalize()) {
+    if (fuse_finalize_ && !ext_on_ && !comm_ && csc_.can_fuse_finalize()) {
         PROF(KernelProfiler::K_FCSC, launch_flat_fused(FM_FCSC, csc_.view, packA_.get(), packB_.get(), fv, st_));
     } else {
         PROF(KernelProfiler::K_FCSC, launch_flat(FM_FCSC, csc_.view, packA_.get(), packB_.get(), 0, st_));
         MFX_TRY(finalize_cols(fv));
     }
     // per-row scalars of the CSR pass are exactly packA (u_prev_new, u_t_old), indexed by row
-    FinalizeArgs fu;
+    FinalizeArgs fu = fin_base();
     fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
-    if (fuse_finalize_ && csr_.can_fuse_finalize()) {
+    if (fuse_finalize_ && !ext_on_ && csr_.can_fuse_finalize()) {
         PROF(KernelProfiler::K_FCSR, launch_flat_fused(FM_FCSR, csr_.view, packC_.get(), packA_.get(), fu, st_));
     } else {
         PROF(KernelProfiler::K_FCSR, launch_flat(FM_FCSR, csr_.view, packC_.get(), packA_.get(), 0, st_));
         PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, fu, st_));
     }
 
-    for (int it = 2; it <= p_.maxinneriter; ++it) {  // remaining inner iterations: read-only sweeps
+    bool stop = false;
+    MFX_TRY(inner_stop(t, 1, &stop));
+    for (int it = 2; it <= p_.maxinneriter && !stop; ++it) {  // remaining inner iterations: read-only sweeps
         PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csc_.view, Wt(t), nullptr, 0, st_));
-        FinalizeArgs f2; f2.lambda = p_.lambda; f2.out_vec = Ht(t);
+        FinalizeArgs f2 = fin_base(); f2.out_vec = Ht(t);
         MFX_TRY(finalize_cols(f2));
         PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csr_.view, Ht(t), nullptr, 0, st_));
-        FinalizeArgs f3; f3.lambda = p_.lambda; f3.out_vec = Wt(t);
+        FinalizeArgs f3 = fin_base(); f3.out_vec = Wt(t);
         PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, f3, st_));
+        MFX_TRY(inner_stop(t, it, &stop));
     }
     if (p_.maxinneriter > 1) {  // the packs must carry the FINAL (u_t, v_t)
         PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(t), Wt(next), packA_.get(), st_));
@@ -805,7 +904,7 @@ int CcdSolver::flush_pending() {
 }
 
 int CcdSolver::sweep(SegStreamStore& s, const float* vec, float* out, bool is_col_side) {
-    FinalizeArgs f;
+    FinalizeArgs f = fin_base();
     f.lambda = p_.lambda;
     f.out_vec = out;
     if (scatter_) {  // sums over columns stream the row-major store (vec = u, by row), and vice versa
@@ -850,9 +949,11 @@ int CcdSolver::rank_as_written(uint32_t t, bool add_back) {
         MFX_TRY(resid(csc_, u, v, 1));
         MFX_TRY(resid(csr_, v, u, 1));
     }
-    for (int it = 1; it <= p_.maxinneriter; ++it) {
+    bool stop = false;
+    for (int it = 1; it <= p_.maxinneriter && !stop; ++it) {
         MFX_TRY(sweep(csc_, u, v, true));   // v <- rank-one over columns, using u
         MFX_TRY(sweep(csr_, v, u, false));  // u <- rank-one over rows, using the new v
+        MFX_TRY(inner_stop(t, it, &stop));
     }
     MFX_TRY(resid(csc_, u, v, 0));
     MFX_TRY(resid(csr_, v, u, 0));
@@ -882,7 +983,7 @@ int CcdSolver::test_rmse(double* rmse_out) {
 // captured once and replayed: one host call per outer iteration instead of 4k.  Matters when the
 // kernels are a few microseconds long (ML-100K / ML-1M sized inputs); irrelevant at Netflix size.
 int CcdSolver::enqueue_outer_iteration(int64_t oiter) {
-    const bool graphable = p_.schedule == 1 && p_.graph >= 0 && !comm_ && !prof_.enabled() && !graph_failed_;
+    const bool graphable = p_.schedule == 1 && p_.graph >= 0 && !comm_ && !prof_.enabled() && !graph_failed_ && !ext_on_;
     if (graphable && graph_exec_) {
         MFX_HIP(hipGraphLaunch(graph_exec_, st_));
         pending_sub_ = (int32_t) k_ - 1;
@@ -896,8 +997,27 @@ int CcdSolver::enqueue_outer_iteration(int64_t oiter) {
         return enqueue_outer_iteration(oiter);
     }
     int rc = MFX_OK;
-    for (uint32_t t = 0; t < k_ && rc == MFX_OK; ++t)
-        rc = p_.schedule == 0 ? rank_as_written(t, oiter > 1) : rank_fused(t);
+    cur_oiter_ = oiter;
+    fundec_max_ = 0.0;
+    early_stop_ = 0;
+    uint32_t done = 0;
+    for (uint32_t t = 0; t < k_ && rc == MFX_OK; ++t) {
+        if (p_.eps > 0.f && early_stop_ >= 5) break;  // LIBPMF: five ranks stopped in their first inner iteration
+        if (p_.rank_trace) rc = trace_begin(t);
+        if (rc == MFX_OK) rc = p_.schedule == 0 ? rank_as_written(t, oiter > 1) : rank_fused(t);
+        if (rc == MFX_OK && p_.rank_trace) rc = trace_end(t);
+        ++done;
+    }
+    if (rc == MFX_OK && done < k_ && p_.schedule == 1 && pending_sub_ >= 0) {
+        // the next outer iteration starts at rank 0, not at the rank the packs were primed for
+        const uint32_t last = (uint32_t) pending_sub_;
+        PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(last), Wt(0), packA_.get(), st_));
+        PROF(KernelProfiler::K_PACK, launch_pack2(n_, Ht(last), Ht(0), packB_.get(), st_));
+    }
+    if (ext_on_) {
+        trace_done_.push_back((int32_t) done);
+        if (p_.rank_trace) { trace_rmse_.resize(trace_done_.size() * k_, std::nan("")); trace_secs_.resize(trace_done_.size() * k_, 0.0); }
+    }
     if (!capture) return rc;
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(st_, &g);
@@ -917,6 +1037,7 @@ int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
     MFX_REQUIRE(n_outer >= 0, "n_outer must be >= 0");
     MFX_REQUIRE(factors_set_, "mfx_ccd_iterate: call mfx_ccd_set_factors first");
     MFX_TRY(use_device(device_));
+    trace_rmse_.clear(); trace_secs_.clear(); trace_done_.clear();
     if (comm_ && !comm_warm_ && n_outer > 0) {
         // RCCL builds its rings / connections lazily, inside the first collective of a given size class:
         // take that hit before the first timed iteration, with an all-reduce of the (still zero) column

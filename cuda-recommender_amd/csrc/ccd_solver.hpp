@@ -95,6 +95,9 @@ public:
     int get_residual(float* csc_val, float* csr_val);
     KernelProfiler& profiler() { return prof_; }
     int set_profile(bool on);
+    // per-rank trace of the last iterate() call (rank_trace): [outer iterations][k] RMSE of calrmse_r1 and seconds
+    // (NaN / 0 for ranks the eps rule skipped), ranks updated per outer iteration
+    int rank_trace(int cap, double* rmse, double* seconds, int iters_cap, int32_t* ranks_done) const;
     void layout_info(int side, int32_t out[4]) const {
         const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
         out[0] = (int32_t) v.npanels; out[1] = (int32_t) v.panel_rows; out[2] = v.scatter ? (v.seg_delta ? 2 : 3) : v.lds_panels ? 1 : 0; out[3] = (int32_t) v.tiles_per_span;
@@ -104,6 +107,21 @@ private:
     CcdSolver() = default;
     int init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space,
              const mfx_shard* shard);
+    // ---- opt-in extensions: the flags the reference parses and ignores (mfx_params.do_nmf / eps / rank_trace) ----
+    bool ext_on_ = false;
+    FinalizeArgs fin_base() const;     // lambda + the extension fields every finalize of this solver carries
+    int inner_stop(uint32_t t, int it, bool* stop);   // eps: LIBPMF's rule after one inner iteration
+    int trace_begin(uint32_t t);
+    int trace_end(uint32_t t);
+    DevBuf<double> fundec_seg_, fundec_sum_, r1_sum_;
+    DevBuf<float> old_w_, old_h_, test_resid_;
+    bool test_resid_valid_ = false;
+    int64_t cur_oiter_ = 0;
+    double fundec_max_ = 0.0;
+    int early_stop_ = 0;
+    hipEvent_t ev_rank_[2] = {nullptr, nullptr};
+    std::vector<double> trace_rmse_, trace_secs_;
+    std::vector<int32_t> trace_done_;
     bool fuse_finalize_ = false;  // MFX_FUSE_FINALIZE=1 / 2: finalize inside the fused passes (bit-identical; measured slower)
     int rank_fused(uint32_t t);
     int rank_as_written(uint32_t t, bool add_back);

@@ -41,6 +41,7 @@ public:
     int panel_rows = 0;
     int layout_build = 0; // mfx_params.layout_build
     int n_gpus = 1;  // -nGPUs: user-row-block shards, one per GPU (CCD++ only)
+    int libpmf_flags = 0;  // -libpmf_flags 1: -e / -N / -p / -q take their LIBPMF meaning (the reference ignores them; so does the default)
     parameter() { snprintf(src_dir, sizeof(src_dir), "../data/simple"); }
 };
 

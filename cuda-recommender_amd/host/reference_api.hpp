@@ -37,6 +37,9 @@ inline mfx_params params_of(const parameter& p) {
     q.verbose = 1;  // the reference wrappers always print the per-iteration line
 #ifndef MFX_SHIM_EXTERNAL_TYPES  // knobs only this repository's `parameter` has
     q.device = p.device; q.schedule = p.schedule; q.kernel_variant = p.kernel_variant; q.panel_rows = p.panel_rows; q.layout_build = p.layout_build;
+    if (p.libpmf_flags) {  // opt-in: the reference reads none of these (src/pmf.h:33-36)
+        q.do_nmf = p.do_nmf; q.eps = p.eps; q.rank_trace = (p.verbose && p.do_predict) ? 1 : 0;
+    }
 #endif
     return q;
 }

@@ -163,7 +163,10 @@ void exit_with_help() {
            "    -schedule s : 1 fused passes (default), 0 one launch per reference kernel\n"
            "    -panel rows : LDS panel size, 0 auto, -1 off\n"
            "    -nGPUs n : CCD++ over n user-row-block shards, one GPU each (RCCL all-reduce per inner iteration)\n"
-           "    -save file : write W then H in the reference's model format (save_mat_t)\n");
+           "    -save file : write W then H in the reference's model format (save_mat_t)\n"
+           "    -libpmf_flags 1 : honour -e, -N and -p/-q with their LIBPMF 1.41 meaning (CCD++, one GPU): function-decrease\n"
+           "                      stopping rule, non-negative factors, per-rank test RMSE lines.  Default 0: parsed and\n"
+           "                      ignored, like the reference does\n");
     exit(EXIT_FAILURE);
 }
 
@@ -181,6 +184,7 @@ parameter parse_command_line(int argc, char** argv) {
         else if (!strcmp(flag, "-panel")) param.panel_rows = atoi(argv[i]);
         else if (!strcmp(flag, "-layout_build")) param.layout_build = atoi(argv[i]);
         else if (!strcmp(flag, "-nGPUs")) param.n_gpus = atoi(argv[i]);
+        else if (!strcmp(flag, "-libpmf_flags")) param.libpmf_flags = atoi(argv[i]);
         else if (!strcmp(flag, "-save")) { /* handled by main (it rescans argv) */ }
         else if (!strcmp(flag, "-CUDA") || !strcmp(flag, "-HIP")) { param.enable_cuda = true; --i; }  // valueless: give it back
         else if (!strcmp(flag, "-OMP")) { param.enable_omp = true; --i; }

@@ -33,7 +33,8 @@ class mfx_params(C.Structure):
                 ("nBlocks", C.c_uint32), ("nThreadsPerBlock", C.c_uint32), ("verbose", C.c_int32),
                 ("device", C.c_int32), ("schedule", C.c_int32), ("kernel_variant", C.c_int32),
                 ("profile", C.c_int32), ("tiles_per_span", C.c_int32), ("panel_rows", C.c_int32),
-                ("wg_waves", C.c_int32), ("graph", C.c_int32), ("layout_build", C.c_int32)]
+                ("wg_waves", C.c_int32), ("graph", C.c_int32), ("layout_build", C.c_int32),
+                ("do_nmf", C.c_int32), ("eps", C.c_float), ("rank_trace", C.c_int32)]
 
 
 class mfx_iter_report(C.Structure):
@@ -73,6 +74,7 @@ SIGNATURES = {
     "mfx_ccd_kernel_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), f64p, i64p]),
     "mfx_ccd_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "mfx_ccd_layout_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
+    "mfx_ccd_rank_trace": (C.c_int, [C.c_void_p, C.c_int, f64p, f64p, C.c_int, C.POINTER(C.c_int32)]),
     "mfx_ccd_destroy": (C.c_int, [C.c_void_p]),
     "mfx_als_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(mfx_csx), C.POINTER(mfx_coo),
                                  C.POINTER(mfx_params), C.c_int]),

@@ -59,6 +59,9 @@ class parameter:
         self.graph = 0
         self.layout_build = 0
         self.log = 0  # print the reference's per-iteration "[-INFO-]" line
+        # opt-in: give eps / do_nmf / (verbose and do_predict) their LIBPMF meaning.  The reference parses them and
+        # reads none (src/pmf.h:33-36), so by default they are ignored here too.
+        self.libpmf_flags = 0
 
     def to_c(self) -> L.mfx_params:
         p = L.mfx_params()
@@ -69,6 +72,9 @@ class parameter:
         p.kernel_variant, p.profile, p.tiles_per_span = int(self.kernel_variant), int(self.profile), int(self.tiles_per_span)
         p.panel_rows, p.wg_waves, p.graph = int(self.panel_rows), int(self.wg_waves), int(self.graph)
         p.layout_build = int(self.layout_build)
+        if self.libpmf_flags:
+            p.do_nmf, p.eps = int(self.do_nmf), float(self.eps)
+            p.rank_trace = 1 if (self.verbose and self.do_predict) else 0
         return p
 
 
@@ -378,6 +384,17 @@ class CcdSolver:
         a, b = np.empty(nnz, np.float32), np.empty(nnz, np.float32)
         L.check(L.lib().mfx_ccd_get_residual(self.handle, _vp(a), _vp(b)))
         return a, b
+
+    def rank_trace(self, n_outer: int, k: int):
+        """(rmse[n_outer, k], seconds[n_outer, k], ranks_done[n_outer]) of the last iterate() call (parameter.libpmf_flags
+        with verbose and do_predict: calrmse_r1 after every rank; NaN where the eps rule skipped a rank)."""
+        rm = np.full((n_outer, k), np.nan, np.float64)
+        sec = np.zeros((n_outer, k), np.float64)
+        done = np.zeros(n_outer, np.int32)
+        n = L.lib().mfx_ccd_rank_trace(self.handle, n_outer * k, rm.ctypes.data_as(L.f64p), sec.ctypes.data_as(L.f64p), n_outer,
+                                       done.ctypes.data_as(C.POINTER(C.c_int32)))
+        L.check(min(n, 0))
+        return rm[:n], sec[:n], done[:n]
 
     def set_profile(self, on: bool):
         L.check(L.lib().mfx_ccd_set_profile(self.handle, 1 if on else 0))

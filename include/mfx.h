@@ -101,6 +101,17 @@ typedef struct mfx_params {
                                   allows it (inside every segment the entries of one panel are consecutive, e.g.
                                   ascending indices -- what every CSR/CSC converter produces), else on the host;
                                   1 = host builder; 2 = GPU builder or MFX_ERR_INVALID */
+    /* ---- opt-in extensions, all 0 by default.  The reference PARSES -N, -e, -p, -q (src/pmf.h:33-36) and reads none
+     * of them in its solvers, so a drop-in must ignore them by default too; set these to give them the meaning they
+     * have in LIBPMF 1.41's ccd-r1.cpp, of which the reference is a fork (CCD++ only, single GPU for eps / rank_trace).
+     * do_nmf and eps are "parity unpinned" (no code or fixture in the reference tree; checked against the oracle's
+     * restatement of the published algorithm); rank_trace is the reference's own calrmse_r1 (src/tools.cpp:261-270),
+     * whose call site is commented out at src/CCD.cpp:141-148. */
+    int32_t do_nmf;            /* -N: new coordinate values are clamped at 0 (non-negative factorisation) */
+    float eps;                 /* -e: > 0 enables the function-decrease stopping rule of the inner iterations (and of the
+                                  rank loop after five ranks that stop at once); costs one host sync per inner iteration */
+    int32_t rank_trace;        /* -p with -q: test RMSE after every rank (mfx_ccd_rank_trace); with verbose also printed
+                                  as the reference's commented line "iter %d rank %d time %f rmse %f" */
 } mfx_params;
 
 /* One outer iteration's numbers == the fields of the reference's log line
@@ -166,6 +177,11 @@ int mfx_ccd_get_residual(mfx_ccd_t s, float* csc_val, float* csr_val);
  * solver's stream: names[i] / seconds[i] / launches[i] for i < returned count (<= cap). */
 int mfx_ccd_kernel_times(mfx_ccd_t s, int cap, const char** names, double* seconds,
                          int64_t* launches);
+/* Per-rank trace of the last mfx_ccd_iterate call (mfx_params.rank_trace, and the ranks the eps rule let run):
+ * rmse / seconds are [outer iterations of that call][k] (up to cap entries; NaN / 0 for skipped ranks), ranks_done
+ * [iters_cap] the number of ranks updated per outer iteration.  Any pointer may be NULL.  Returns the number of
+ * outer iterations recorded (0 when no extension was on). */
+int mfx_ccd_rank_trace(mfx_ccd_t s, int cap, double* rmse, double* seconds, int iters_cap, int32_t* ranks_done);
 /* Turns the per-launch event bracketing (mfx_params.profile) on or off between iterate calls. */
 int mfx_ccd_set_profile(mfx_ccd_t s, int on);
 /* Layout the solver chose for one residual copy (side 0 = CSC / column segments, 1 = CSR / row

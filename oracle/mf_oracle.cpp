@@ -171,6 +171,66 @@ void als_half(long nseg, const unsigned* ptr, const unsigned* idx, const float* 
     }
 }
 
+
+/* ---------------------------------------------------------------------------------------------
+ * The flags the reference parses and never reads (src/pmf.h:33-36: eps, do_predict, verbose,
+ * do_nmf).  What is PINNED here: calrmse_r1 -- real code in the reference, src/tools.cpp:261-270,
+ * with its intended call site left in a comment at src/CCD.cpp:141-148 (verbose && do_predict:
+ * per-rank "rmse" from an incrementally updated test residual).  What is NOT pinned ("parity
+ * unpinned": no code, test or fixture for it anywhere under /root/reference): the meaning of eps
+ * and do_nmf.  The reference is a fork of LIBPMF 1.41's ccd-r1.cpp, where they are
+ *   do_nmf : the new coordinate value is clamped at 0;
+ *   eps    : per update fundec = h * (old - new)^2 (clamped update: -2 g old + h old^2) with
+ *            h = lambda |Omega| + sum u^2; an inner iteration's fundec is summed over its v- and
+ *            u-update; the inner loop of a rank stops when that sum drops below eps * fundec_max
+ *            (the running maximum over the outer iteration, the very first inner iteration of
+ *            the first rank of the first outer iteration excepted), a rank that stops in its
+ *            first inner iteration counts as an early stop, and the rank loop of an outer
+ *            iteration ends after five of them.
+ * Restated from that published algorithm; arithmetic in the reference's fp32 with the fundec
+ * sums in double. */
+inline float rank_one_column_ext(const unsigned* ptr, const unsigned* idx, const float* val, long c, const float* vec,
+                                 float lambda_scaled, float old, int do_nmf, double* fundec) {
+    const unsigned lo = ptr[c], hi = ptr[c + 1];
+    if (lo == hi) return 0.0f;
+    float g = 0.0f, h = lambda_scaled;
+    for (unsigned p = lo; p < hi; ++p) {
+        const float x = vec[idx[p]];
+        g += x * val[p];
+        h += x * x;
+    }
+    float x = g / h;
+    if (do_nmf && x < 0.0f) {
+        x = 0.0f;
+        *fundec += -2.0 * (double) g * (double) old + (double) h * (double) old * (double) old;
+    } else {
+        const double delta = (double) old - (double) x;
+        *fundec += (double) h * delta * delta;
+    }
+    return x;
+}
+
+inline double sweep_ext(long ncols, const unsigned* ptr, const unsigned* idx, const float* val, const float* vec,
+                        float lambda, float* out, int do_nmf) {
+    double fundec = 0.0;
+#pragma omp parallel for ORC_SCHED reduction(+ : fundec)
+    for (long c = 0; c < ncols; ++c)
+        out[c] = rank_one_column_ext(ptr, idx, val, c, vec, lambda * (ptr[c + 1] - ptr[c]), out[c], do_nmf, &fundec);
+    return fundec;
+}
+
+/* src/tools.cpp:261-270 */
+inline double calrmse_r1(long nnz_test, const unsigned* row, const unsigned* col, float* resid, const float* Wt,
+                         const float* Ht, const float* oldWt, const float* oldHt) {
+    double rmse = 0;
+#pragma omp parallel for reduction(+ : rmse)
+    for (long q = 0; q < nnz_test; ++q) {
+        resid[q] -= Wt[row[q]] * Ht[col[q]] - oldWt[row[q]] * oldHt[col[q]];
+        rmse += resid[q] * resid[q];
+    }
+    return sqrt(rmse / nnz_test);
+}
+
 } // namespace
 
 extern "C" {
@@ -254,6 +314,56 @@ void orc_ccdr1(long m, long n, long nnz, const unsigned* csc_col_ptr, const unsi
             rmse_out[oiter - 1] =
                 nnz_test > 0 ? orc_calrmse(nnz_test, test_row, test_col, test_val, W, H, m, n, k, 0)
                              : 0.0;
+    }
+}
+
+
+void orc_ccdr1_ext(long m, long n, const unsigned* csc_col_ptr, const unsigned* csc_row_idx, float* csc_val,
+                   const unsigned* csr_row_ptr, const unsigned* csr_col_idx, float* csr_val, float* W, float* H, long k,
+                   float lambda, int maxiter, int maxinneriter, int threads, long nnz_test, const unsigned* test_row,
+                   const unsigned* test_col, const float* test_val, int do_nmf, float eps, double* rmse_out,
+                   double* rank_rmse_out, int* ranks_done_out) {
+    omp_set_num_threads(threads > 0 ? threads : 1);
+    memset(H, 0, sizeof(float) * (size_t) k * (size_t) n);
+    std::vector<float> u(m), v(n), oldu(m), oldv(n), tres(test_val, test_val + nnz_test);
+    for (int oiter = 1; oiter <= maxiter; ++oiter) {
+        double fundec_max = 0;
+        int early_stop = 0, done = 0;
+        for (long t = 0; t < k; ++t) {
+            if (eps > 0 && early_stop >= 5) break;
+            float* Wt = W + t * m;
+            float* Ht = H + t * n;
+            memcpy(u.data(), Wt, sizeof(float) * m);
+            memcpy(v.data(), Ht, sizeof(float) * n);
+            oldu = u;
+            oldv = v; /* zero in the first outer iteration: H starts at 0 */
+            if (oiter > 1) {
+                residual_update(n, csc_col_ptr, csc_row_idx, csc_val, Wt, Ht, true);
+                residual_update(m, csr_row_ptr, csr_col_idx, csr_val, Ht, Wt, true);
+            }
+            for (int it = 1; it <= maxinneriter; ++it) {
+                double cur = sweep_ext(n, csc_col_ptr, csc_row_idx, csc_val, u.data(), lambda, v.data(), do_nmf);
+                cur += sweep_ext(m, csr_row_ptr, csr_col_idx, csr_val, v.data(), lambda, u.data(), do_nmf);
+                if (eps > 0) {
+                    if (cur < fundec_max * (double) eps) {
+                        if (it == 1) ++early_stop;
+                        break;
+                    }
+                    if (!(oiter == 1 && t == 0 && it == 1)) fundec_max = cur > fundec_max ? cur : fundec_max;
+                }
+            }
+            memcpy(Wt, u.data(), sizeof(float) * m);
+            memcpy(Ht, v.data(), sizeof(float) * n);
+            residual_update(n, csc_col_ptr, csc_row_idx, csc_val, u.data(), v.data(), false);
+            residual_update(m, csr_row_ptr, csr_col_idx, csr_val, v.data(), u.data(), false);
+            if (rank_rmse_out && nnz_test > 0)
+                rank_rmse_out[(size_t) (oiter - 1) * k + t] =
+                    calrmse_r1(nnz_test, test_row, test_col, tres.data(), u.data(), v.data(), oldu.data(), oldv.data());
+            ++done;
+        }
+        if (ranks_done_out) ranks_done_out[oiter - 1] = done;
+        if (rmse_out)
+            rmse_out[oiter - 1] = nnz_test > 0 ? orc_calrmse(nnz_test, test_row, test_col, test_val, W, H, m, n, k, 0) : 0.0;
     }
 }
 

@@ -123,6 +123,26 @@ def ccdr1(d, W, k, lam, maxiter, maxinner, threads=1):
     return W, H, rmse, times, csc_val, csr_val
 
 
+def ccdr1_ext(d, W, k, lam, maxiter, maxinner, threads=1, do_nmf=0, eps=0.0):
+    """ccdr1 with do_nmf / eps (LIBPMF 1.41 meaning; parity unpinned) and the per-rank calrmse_r1 trace (pinned:
+    src/tools.cpp:261-270).  Returns (W, H, rmse[maxiter], rank_rmse[maxiter, k], ranks_done[maxiter])."""
+    W = np.array(W, np.float32, copy=True, order="C").reshape(k, d.rows)
+    H = np.zeros((k, d.cols), np.float32)
+    csc_val, csr_val = d.csc_val.copy(), d.csr_val.copy()
+    rmse = np.zeros(maxiter, np.float64)
+    rank_rmse = np.full((maxiter, k), np.nan, np.float64)
+    done = np.zeros(maxiter, np.int32)
+    lib().orc_ccdr1_ext(C.c_long(d.rows), C.c_long(d.cols),
+                        _p(d.csc_col_ptr, _u32p), _p(d.csc_row_idx, _u32p), _p(csc_val, _f32p),
+                        _p(d.csr_row_ptr, _u32p), _p(d.csr_col_idx, _u32p), _p(csr_val, _f32p),
+                        _p(W, _f32p), _p(H, _f32p), C.c_long(k), C.c_float(lam), C.c_int(maxiter),
+                        C.c_int(maxinner), C.c_int(threads), C.c_long(d.nnz_test),
+                        _p(d.test_row, _u32p), _p(d.test_col, _u32p), _p(d.test_val, _f32p),
+                        C.c_int(do_nmf), C.c_float(eps), _p(rmse, _f64p), _p(rank_rmse, _f64p),
+                        done.ctypes.data_as(C.POINTER(C.c_int)))
+    return W, H, rmse, rank_rmse, done
+
+
 def gramian(idx, X, k) -> np.ndarray:
     A = np.empty((k, k), np.float32)
     lib().orc_gramian(C.c_long(idx.shape[0]), _p(_chk(idx, np.uint32), _u32p), _p(_chk(X, np.float32), _f32p),

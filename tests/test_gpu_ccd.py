@@ -422,3 +422,93 @@ def test_fused_finalize_equals_the_separate_kernel(mfx, medium, monkeypatch, pan
         for a, b in zip(o[:4], outs[2][:4]):
             assert np.array_equal(bits(a), bits(b))
         assert np.array_equal(o[4], outs[2][4])
+
+
+# ---- the flags the reference parses and ignores (-N, -e, -p/-q), opt-in with their LIBPMF meaning ---------------------
+def _ext_params(mfx, k, lam, t, T, schedule, variant, panel_rows=0, **ext):
+    p = _params(mfx, k, lam, t, T, schedule, variant, panel_rows=panel_rows)
+    p.libpmf_flags = 1
+    p.eps = 0.0
+    for a, b in ext.items():
+        setattr(p, a, b)
+    return p
+
+
+@pytest.mark.parametrize("schedule,variant,panel_rows", [(1, 1, 0), (1, 1, 64), (0, 1, 0), (0, 0, 0), (1, 2, 0)])
+def test_rank_trace_is_calrmse_r1(mfx, orc, medium, schedule, variant, panel_rows):
+    """-p 1 -q 1 under libpmf_flags: the per-rank RMSE of the reference's calrmse_r1 (src/tools.cpp:261-270; its call
+    site is the commented block src/CCD.cpp:141-148).  Checked against the oracle's restatement rank by rank, and --
+    the property that pins it to the reference's own outputs -- the value after the LAST rank of an outer iteration is
+    that iteration's test RMSE (the incrementally updated test residual equals the directly computed one)."""
+    d = medium
+    k, lam, t, T = 5, 0.05, 3, 2
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, trace_ref, done_ref = orc.ccdr1_ext(d, W0, k, lam, t, T, 2)
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _ext_params(mfx, k, lam, t, T, schedule, variant, panel_rows, verbose=1, do_predict=1))
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    trace, secs, done = s.rank_trace(t, k)
+    W, H = s.get_factors()
+    s.close()
+    assert list(done) == [k] * t and trace.shape == (t, k) and np.all(secs > 0)
+    assert np.all(np.abs(trace - trace_ref) < 1e-4), (trace, trace_ref)
+    rm = np.array([r.rmse for r in rep])
+    assert np.all(np.abs(trace[:, -1] - rm) < 2e-6), (trace[:, -1], rm)
+    assert np.all(np.abs(rm - rmse_ref) < 1e-4)
+
+
+@pytest.mark.parametrize("schedule,variant,panel_rows", [(1, 1, 0), (1, 1, 64), (0, 1, 0), (1, 2, 0)])
+def test_nmf_projection_vs_oracle(mfx, orc, medium, schedule, variant, panel_rows):
+    """-N 1 under libpmf_flags ("parity unpinned": no code for it in the reference tree; LIBPMF's meaning, checked
+    against the oracle's restatement): every factor entry is >= 0, RMSE trace and factors as the oracle's."""
+    d = medium
+    k, lam, t = 5, 0.05, 3
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, _, _ = orc.ccdr1_ext(d, W0, k, lam, t, 1, 2, do_nmf=1)
+    assert (Wr < 0).sum() == 0 and (Hr < 0).sum() == 0
+    _, _, rmse_plain, _, _ = orc.ccdr1_ext(d, W0, k, lam, t, 1, 2)
+    assert np.abs(rmse_plain - rmse_ref).max() > 1e-5  # the projection is active on this input
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _ext_params(mfx, k, lam, t, 1, schedule, variant, panel_rows, do_nmf=1))
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    W, H = s.get_factors()
+    s.close()
+    assert W.min() >= 0 and H.min() >= 0
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-4)
+    scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
+    assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale
+    # and the default ignores the flag, like the reference
+    p = _params(mfx, k, lam, t, 1, schedule, variant, panel_rows=panel_rows)
+    p.do_nmf = 1
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), p)
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    s.close()
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_plain) < 1e-4)
+
+
+@pytest.mark.parametrize("schedule,variant,panel_rows,eps", [(1, 1, 0, 0.05), (1, 1, 64, 0.05), (0, 1, 0, 0.05), (1, 2, 0, 0.05), (1, 1, 0, 0.6)])
+def test_eps_stopping_rule_vs_oracle(mfx, orc, medium, schedule, variant, panel_rows, eps):
+    """-e under libpmf_flags ("parity unpinned", LIBPMF's rule restated in the oracle): inner iterations stop when the
+    function decrease falls below eps x its running maximum; five ranks that stop in their first inner iteration end
+    the outer iteration.  Same ranks skipped, same RMSE trace and factors as the oracle."""
+    d = medium
+    k, lam, t, T = 8, 0.05, 4, 3
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, trace_ref, done_ref = orc.ccdr1_ext(d, W0, k, lam, t, T, 2, eps=eps)
+    _, _, rmse_plain, _, _ = orc.ccdr1_ext(d, W0, k, lam, t, T, 2)
+    assert np.abs(rmse_plain - rmse_ref).max() > 1e-6  # the rule fires on this input
+    if eps > 0.5:
+        assert done_ref.min() < k  # ... and cuts the rank loop short
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _ext_params(mfx, k, lam, t, T, schedule, variant, panel_rows, eps=eps, verbose=1, do_predict=1))
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    trace, secs, done = s.rank_trace(t, k)
+    W, H = s.get_factors()
+    s.close()
+    assert list(done) == list(done_ref), (done, done_ref)
+    assert np.array_equal(np.isnan(trace), np.isnan(trace_ref))
+    assert np.nanmax(np.abs(trace - trace_ref)) < 1e-4
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-4)
+    scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
+    assert np.abs(W - Wr).max() < 2e-3 * scale and np.abs(H - Hr).max() < 2e-3 * scale

@@ -151,3 +151,26 @@ def test_bench_contract_line():
     assert d["rank_one_kernel"]["kernel"] == "ccd_flat_sweep" and d["rank_one_kernel"]["launches"] == 16
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert d["layout"]["csc"]["kind"] in ("lds", "cache", "plain")
+
+
+def test_mfx_train_ignores_dead_flags_unless_asked(tmp_path):
+    """-e / -N / -p / -q are parsed by the reference and read by none of its solvers (src/pmf.h:33-36): on the same
+    command line mfx_train prints the golden RMSE trace with or without them.  With -libpmf_flags 1 they take their
+    LIBPMF meaning: -p 1 -q 1 prints the line of the reference's commented block (src/CCD.cpp:141-148) after every
+    rank, and the last rank's value of an outer iteration is that iteration's RMSE."""
+    import mfx
+    g, d = load_golden("small")
+    mfx.dataset.write_dataset_dir(str(tmp_path / "ds"), d)
+    exe = os.path.join(ROOT, "cuda-recommender_amd", "mfx_train")
+    k, lam, t = int(g["k"][0]), float(g["lam"][0]), int(g["ccd_T1__maxiter"][0])
+    base = [exe, "-CUDA", "-k", str(k), "-l", repr(lam), "-t", str(t), "-T", "1", "-e", "0.5", "-N", "1", "-p", "1", "-q", "1"]
+    r = subprocess.run(base + [str(tmp_path / "ds")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rmse = np.array([float(x) for x in re.findall(r"\[-INFO-\] iteration num \d+ .*RMSE=([0-9.]+)", r.stdout)])
+    assert np.all(np.abs(rmse - g["ccd_T1__rmse"]) < 1e-4) and not re.search(r"^iter \d+ rank", r.stdout, re.M)
+    r = subprocess.run(base[:-8] + ["-p", "1", "-q", "1", "-libpmf_flags", "1", str(tmp_path / "ds")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = re.findall(r"^iter (\d+) rank (\d+) time ([0-9.]+) rmse ([0-9.]+)", r.stdout, re.M)
+    assert [(int(a), int(b)) for a, b, _, _ in lines] == [(i, j) for i in range(1, t + 1) for j in range(1, k + 1)]
+    last = np.array([float(x[3]) for x in lines]).reshape(t, k)[:, -1]
+    assert np.all(np.abs(last - g["ccd_T1__rmse"]) < 1e-4), (last, g["ccd_T1__rmse"])

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(mfx):
     import ctypes as C
     from mfx import _lib as L
     assert C.sizeof(L.mfx_csx) == 72 and C.sizeof(L.mfx_coo) == 32
-    assert C.sizeof(L.mfx_params) == 64 and C.sizeof(L.mfx_iter_report) == 32
+    assert C.sizeof(L.mfx_params) == 76 and C.sizeof(L.mfx_iter_report) == 32
     p = L.mfx_params()
     mfx.lib().mfx_params_default(C.byref(p))
     # reference defaults, src/pmf.h:26-42

@@ -93,3 +93,19 @@ def test_als_half_equals_full_first_half(golden):
     assert np.array_equal(bits(W1), bits(W)) and np.array_equal(bits(H1), bits(H))
     empty = np.diff(d.csr_row_ptr.astype(np.int64)) == 0
     assert np.all(W1[empty] == 0)  # zero-row rule, src/ALS.cpp:151-157
+
+
+@pytest.mark.parametrize("tag", ["ccd_T1", "ccd_T3"])
+def test_ccdr1_ext_with_everything_off_is_ccdr1_and_its_rank_trace_ends_on_the_iteration_rmse(golden, tag):
+    """orc_ccdr1_ext (the flags the reference parses and ignores, given their LIBPMF meaning) with do_nmf = 0 and
+    eps = 0 must be the pinned ccdr1 bit for bit; and its per-rank calrmse_r1 trace (src/tools.cpp:261-270) must end
+    every outer iteration on the reference's own per-iteration test RMSE -- the incrementally updated test residual
+    IS the residual calrmse recomputes from the factors (fp32 vs f64 accumulation apart)."""
+    name, g, d = golden
+    k, lam = int(g["k"][0]), float(g["lam"][0])
+    t, T = int(g[tag + "__maxiter"][0]), int(g[tag + "__maxinner"][0])
+    W, H, rmse, trace, done = orc.ccdr1_ext(d, g[tag + "__W0"], k, lam, t, T, 2)
+    assert np.array_equal(bits(W), bits(g[tag + "__W"])) and np.array_equal(bits(H), bits(g[tag + "__H"]))
+    assert np.allclose(rmse, g[tag + "__rmse"], rtol=0, atol=5.1e-7) and list(done) == [k] * t  # (the log prints 6 decimals)
+    if d.nnz_test:
+        assert np.all(np.abs(trace[:, -1] - g[tag + "__rmse"]) < 3e-6), (trace[:, -1], g[tag + "__rmse"])
