@@ -13,7 +13,7 @@
 //
 // Tail (per segment, still one wave): accumulators -> LDS (lower triangle only, rows packed and
 // 16-B aligned), + lambda on the diagonal (plain lambda, src/ALS.cpp:120-122), left-looking Cholesky
-// (the reference's row-by-row scheme, src/ALS.cpp:6-23, inner dot product in four partial sums),
+// (the reference's row-by-row scheme, src/ALS.cpp:6-23; dot products fused, one scale by 1/sqrt(pivot) per column),
 // then L z = b and L^T y = z instead of the reference's explicit inverse (same solution up to
 // rounding; tolerance in the tests).
 #include "als_solver.hpp"
@@ -41,32 +41,22 @@ __device__ __forceinline__ float add_rn(float a, float b) {
     return a + b;
 }
 
-// Correctly rounded sqrt for normal-range inputs: v_sqrt_f32 (<= 1 ulp) and the two residual checks of
-// the compiler's own expansion, without its rescaling of inputs below 2^-96 and its zero / inf /
-// NaN pass-through -- a pivot is lambda + a sum of squares; anything else is flagged as an SPD failure
-// by the caller.  Same result as sqrtf() for every input the solver can meet, 9 instead of 20 VALU
-// instructions, 64 times per system.
-__device__ __forceinline__ float sqrt_rn_normal(float x) {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
-    const float s_up = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
-    const float r_dn = __builtin_fmaf(-s_dn, s, x);
-    const float r_up = __builtin_fmaf(-s_up, s, x);
-    float r = r_dn <= 0.f ? s_dn : s;
-    r = r_up > 0.f ? s_up : r;
-    return r;
-}
-
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ f32x2 mul2_rn(f32x2 a, f32x2 b) {
-#pragma clang fp contract(off)
-    return a * b;
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
+
+// 1 / sqrt(x) for a pivot (normal range, > 0): v_rsq_f32 (1 ulp) + one Newton step.  A non-positive or NaN pivot
+// gives NaN / inf, which the caller has already flagged as an SPD failure.
+__device__ __forceinline__ float rsqrt_nr(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float e = __builtin_fmaf(-x * y, y, 1.0f);
+    return __builtin_fmaf(0.5f * y, e, y);
 }
-__device__ __forceinline__ f32x2 add2_rn(f32x2 a, f32x2 b) {
-#pragma clang fp contract(off)
-    return a + b;
+// 1 / x: v_rcp_f32 (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_nr(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
 }
 
 // Blocked MFMA Cholesky for k > 32 (chol_blocked); false = the round-1 row-by-row forms, kept for A/B runs.
@@ -83,6 +73,7 @@ struct AlsArgs {
     const float* val;
     const float* X;    // [x_rows + 1][k]: row x_rows is all zeros (gather target of positions past a segment's end)
     uint32_t x_rows;
+    uint32_t sentinel;  // idx[sentinel] = x_rows, val[sentinel] = 0: what a position past a segment's end loads
     float* Y;
     uint32_t k;
     float lambda;
@@ -168,21 +159,20 @@ __device__ __forceinline__ void chol_panel_pass(float* __restrict__ L, int J, in
 #pragma unroll
         for (int q = 0; q + 4 <= i; q += 4) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(pivrow + q);
-            s01 = add2_rn(s01, mul2_rn(x.lo, r2[q / 2]));
-            s23 = add2_rn(s23, mul2_rn(x.hi, r2[q / 2 + 1]));
+            s01 = fma2(x.lo, r2[q / 2], s01);
+            s23 = fma2(x.hi, r2[q / 2 + 1], s23);
         }
 #pragma unroll
-        for (int q = i & ~3; q < i; ++q) s01.x = add_rn(s01.x, mul_rn(pivrow[q], r2[q / 2][q & 1]));
-        const float sum = sub_rn(r2[i / 2][i & 1], add_rn(add_rn(s01.x, s01.y), add_rn(s23.x, s23.y)));
+        for (int q = i & ~3; q < i; ++q) s01.x = __builtin_fmaf(pivrow[q], r2[q / 2][q & 1], s01.x);
+        const float sum = r2[i / 2][i & 1] - ((s01.x + s01.y) + (s23.x + s23.y));
         float lji;
         if constexpr (DIAG) {
             const float piv = rl(sum, i);  // lane i < 32 owns the diagonal entry
             spd_ok = spd_ok && piv > 0.f;
-            const float pv = sqrt_rn_normal(piv);
-            lji = lane == i ? pv : sum / pv;
+            lji = sum * rsqrt_nr(piv);     // lane i: pivot / sqrt(pivot) = the diagonal entry (see factor_solve, k <= 64)
             if (stores && (h || lane >= i)) blk[i] = lji;
         } else {
-            lji = sum / pivrow[i];
+            lji = sum * rcp_nr(pivrow[i]);
             if (stores) blk[i] = lji;
         }
         r2[i / 2][i & 1] = lji;  // (diagonal block, lanes above the pivot: a slot they never read)
@@ -229,11 +219,12 @@ __device__ void chol_blocked(float* __restrict__ L, bool& spd_ok) {
 }
 
 // LDS image -> + lambda, Cholesky, two triangular solves, Y[seg] <- solution.
-template <int NT>
+// FULL: k == KP known at compile time (the k = 64 kernels: no per-column `i < k` branches, no `lane < k` masks).
+template <int NT, bool FULL = false>
 __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     constexpr int KP = 32 * NT;
     const uint32_t lane = threadIdx.x & 63;
-    const int k = (int) a.k;
+    const int k = FULL ? KP : (int) a.k;
     float* L = lds;
     float* bv = lds + roff(KP);
     __syncthreads();
@@ -277,6 +268,12 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
         auto rl = [](float x, int src_lane) {
             return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
         };
+        // Per column i: dot products as v_pk_fma_f32 (two columns per instruction, fused: one rounding less than the
+        // reference's multiply-then-add), then ONE scale for the whole column: L[j][i] = sum_j * rs with
+        // rs = 1/sqrt(pivot) (v_rsq_f32 + a Newton step, computed redundantly by every lane from the broadcast pivot).
+        // Lane i's own product pivot * rs is the diagonal entry sqrt(pivot) to within an ulp, so there is no select
+        // between "diagonal" and "below", no correctly rounded sqrt and no IEEE division in the loop (they were 21 of
+        // the ~45 VALU instructions of a step; the solves below take 1 / L[i][i] once, in parallel).
         bool spd_ok = true;
 #pragma unroll
         for (int i = 0; i < KP; ++i) {
@@ -285,44 +282,45 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
 #pragma unroll
                 for (int q = 0; q + 4 <= i; q += 4) {
                     const f32x4 x = *reinterpret_cast<const f32x4*>(&L[roff(i) + q]);
-                    s01 = add2_rn(s01, mul2_rn(x.lo, r2[q / 2]));
-                    s23 = add2_rn(s23, mul2_rn(x.hi, r2[q / 2 + 1]));
+                    s01 = fma2(x.lo, r2[q / 2], s01);
+                    s23 = fma2(x.hi, r2[q / 2 + 1], s23);
                 }
 #pragma unroll
-                for (int q = i & ~3; q < i; ++q) s01.x = add_rn(s01.x, mul_rn(rl(r2[q / 2][q & 1], i), r2[q / 2][q & 1]));
-                const float sum = sub_rn(r2[i / 2][i & 1], add_rn(add_rn(s01.x, s01.y), add_rn(s23.x, s23.y)));
+                for (int q = i & ~3; q < i; ++q) s01.x = __builtin_fmaf(rl(r2[q / 2][q & 1], i), r2[q / 2][q & 1], s01.x);
+                const float sum = r2[i / 2][i & 1] - ((s01.x + s01.y) + (s23.x + s23.y));
                 const float piv = rl(sum, i);
                 spd_ok = spd_ok && piv > 0.f;  // wave-uniform; NaN fails the comparison as well
-                const float p = sqrt_rn_normal(piv);
-                const float lji = (int) lane == i ? p : sum / p;
+                const float lji = sum * rsqrt_nr(piv);
                 r2[i / 2][i & 1] = lji;  // lanes j < i: a register slot (column i > j) they never read
                 if ((int) lane >= i && (int) lane < KP) L[roff((int) lane) + i] = lji;
             }
         }
         if (lane == 0 && !spd_ok) atomicAdd(a.spd_fail, 1u);  // one count per system (the k > 64 form counts pivots)
         __syncthreads();
-        // Triangular solves, same arithmetic as the generic loops below but unrolled: the forward pass
-        // takes L[lane][i] from the lane's registers, the backward pass reads row i of L from LDS at a
-        // compile-time offset (lane-strided, conflict-free); no per-step address arithmetic.
+        // Triangular solves on the UNSCALED unknowns: lane i carries z_i * L[i][i] until the very end, so a step is
+        // scale (one multiply for all lanes), broadcast (v_readlane), update (one masked fma) -- no per-step select of
+        // the finished component.  The forward pass takes L[lane][i] from the lane's registers, the backward pass reads
+        // row i of L from LDS at a compile-time offset (lane-strided, conflict-free).  Rows k .. KP-1 are identity rows
+        // with a zero rhs: their updates add exact zeros.
         float z = lane < (uint32_t) k ? bv[lane] : 0.f;
-        const float rp = lane < (uint32_t) k ? 1.0f / L[roff((int) lane) + lane] : 0.f;
+        const float rp = lane < (uint32_t) k ? rcp_nr(L[roff((int) lane) + lane]) : 0.f;
 #pragma unroll
         for (int i = 0; i < KP; ++i) {  // forward: L z = b
             if (i < k) {
-                const float zi = rl(z, i) * rl(rp, i);
-                const float upd = sub_rn(z, mul_rn(r2[i / 2][i & 1], zi));
-                z = (int) lane == i ? zi : ((int) lane > i && (int) lane < k ? upd : z);
+                const float zi = rl(z * rp, i);
+                z = (int) lane > i ? __builtin_fmaf(-r2[i / 2][i & 1], zi, z) : z;
             }
         }
+        z *= rp;  // = the solution of L z = b; the backward pass carries y_i * L[i][i] the same way
 #pragma unroll
         for (int i = KP - 1; i >= 0; --i) {  // backward: L^T y = z
             if (i < k) {
-                const float yi = rl(z, i) * rl(rp, i);
-                const float lij = L[roff(i) + ((int) lane < i ? (int) lane : 0)];
-                const float upd = sub_rn(z, mul_rn(lij, yi));
-                z = (int) lane == i ? yi : ((int) lane < i ? upd : z);
+                const float yi = rl(z * rp, i);
+                const float lij = L[roff(i) + (int) lane];  // lanes >= i read past the row's diagonal: masked below
+                z = (int) lane < i ? __builtin_fmaf(-lij, yi, z) : z;
             }
         }
+        z *= rp;
         if ((int) lane < k) a.Y[(size_t) seg * k + lane] = z;
         return;
     } else {
@@ -390,8 +388,12 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
 
 
 
+// Waves per SIMD the LDS image allows anyway (k = 128: 34 KB per system -> one wave per SIMD; k = 96: two), stated
+// so that the register allocator does not trade the Gramian loop's pipelining for an occupancy it cannot get.
+constexpr int als_waves(int NT) { return NT >= 4 ? 1 : NT == 3 ? 2 : NT == 2 ? 3 : 6; }
+
 template <int NT>
-__global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(als_waves(NT), als_waves(NT)))) void k_als_gram(AlsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63, c31 = lane & 31, h = lane >> 5;
     const uint32_t item = blockIdx.x;
@@ -415,7 +417,12 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
     // Same pipeline as k_als_gram16: indices / ratings two batches ahead, factor rows one batch ahead,
     // every load unconditional -- positions past the segment's end and columns past k gather from the
     // all-zero row X[x_rows].
-    const uint32_t last = it.hi - 1;
+    // A position past the segment's end loads the SENTINEL entry of the index / value arrays (the zero row, rating 0):
+    // a select between two positions of one array.  Written as `q < hi ? idx[q] : x_rows` the conditional is folded
+    // into a select between two ADDRESSES (the index array, the slot holding x_rows) feeding one flat_load -- which
+    // counts on lgkmcnt as well as vmcnt, so every batch began with `s_waitcnt vmcnt(0) lgkmcnt(0)`: all loads in
+    // flight drained, the one issued two instructions earlier included (58 % of the MFMA rate).
+    const uint32_t zrow = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.x_rows);
     uint32_t row_n[U];
     float rv_n[U], rv_c[U];
     float av_n[U][NT];
@@ -423,9 +430,9 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t q = q0 + 2 * u + h;
-            const uint32_t r = a.idx[q < last ? q : last];
-            row_n[u] = q < it.hi ? r : a.x_rows;
-            rv_n[u] = a.val[q < last ? q : last];
+            const uint32_t qe = q < it.hi ? q : a.sentinel;
+            row_n[u] = a.idx[qe];
+            rv_n[u] = a.val[qe];
         }
     };
     auto load_rows = [&]() {
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
             for (int I = 0; I < NT; ++I) {
                 const uint32_t col = I * 32 + c31;
                 const bool in = col < k;
-                av_n[u][I] = a.X[(size_t) (in ? row_n[u] : a.x_rows) * k + (in ? col : 0u)];
+                av_n[u][I] = a.X[(size_t) (in ? row_n[u] : zrow) * k + (in ? col : 0u)];
             }
             rv_c[u] = rv_n[u];
         }
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(64) void k_als_gram(AlsArgs a) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(64) void k_als_reduce(AlsArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(als_waves(NT), als_waves(NT)))) void k_als_reduce(AlsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63;
     if (blockIdx.x >= a.count) return;
@@ -543,8 +550,72 @@ __device__ __forceinline__ void stage_tiles16(f32x4 (&acc)[kTiles16], float (&ba
     }
 }
 
-// 4 waves per SIMD: 125 VGPRs + 16 spilled dwords instead of 132 VGPRs and 3 waves (measured: 16.3 -> 15.6 ms per
-// iteration at the Netflix shape; 5 waves = 96 VGPRs + 162 spills: 21.1 ms)
+// Pipeline state of k_als_gram16: two register sets, used alternately by consecutive 16-row steps (no copies).
+constexpr int kU16 = 4;  // 4-row MFMA groups per step: 16 gathered rows (4 KB) per set
+struct Gram16Regs {
+    uint32_t ix[2][kU16];  // gathered row indices           (stage 0: loaded two steps ahead of their MFMAs)
+    f32x4 av[2][kU16];     // gathered factor-row quarters   (stage 1: one step ahead)
+    float rv[2][kU16];     // ratings                        (stage 1)
+    f32x4 acc[kTiles16];
+    f32x2 bacc[2];         // rhs partial sums of column sets (0, 1) and (2, 3)
+};
+
+// The three stages of one 16-row step s of a work item (entries lo + 16 s + 4 u + g, u = 0..3), each on register
+// set S.  Every load is unconditional and has a wave-uniform base (SGPR pair: the item's first entry, advanced by
+// the scalar unit) plus a lane-constant 32-bit offset plus an immediate -- no per-load address arithmetic on the
+// vector unit.  Positions past the item's end read on into the next segment's entries (or the arrays' zero padding,
+// AlsHalf::build); their ROW OFFSET is replaced by the all-zero row X[x_rows], so they add exact zeros (a rating
+// read from past the end multiplies that zero row).
+template <int S>
+__device__ __forceinline__ void g16_load_idx(Gram16Regs& r, const uint32_t* __restrict__ ibase, uint32_t s, uint32_t g) {
+#pragma unroll
+    for (int u = 0; u < kU16; ++u) r.ix[S][u] = ibase[s * 16 + 4 * u + g];
+}
+template <int S>
+__device__ __forceinline__ void g16_load_rows(Gram16Regs& r, const char* __restrict__ Xb, const float* __restrict__ vbase,
+                                              uint32_t s, uint32_t g, uint32_t len, bool col_ok, uint32_t rowbytes,
+                                              uint32_t lane_off, uint32_t zero_off) {
+#pragma unroll
+    for (int u = 0; u < kU16; ++u) {
+        const bool ok = col_ok && s * 16 + 4 * u + g < len;
+        uint32_t ix = r.ix[S][u];
+        // opaque use: otherwise the index load (only consumed when `ok`) is sunk out of the previous step into a
+        // divergent branch right here, with a full wait behind it
+        asm volatile("" : "+v"(ix));
+        const uint32_t off = ok ? __umul24(ix, rowbytes) + lane_off : zero_off;  // x_rows < 2^24, table < 4 GB (launch_half)
+        r.av[S][u] = *reinterpret_cast<const f32x4*>(Xb + off);
+        r.rv[S][u] = vbase[s * 16 + 4 * u + g];
+    }
+}
+template <int S>
+__device__ __forceinline__ void g16_mfma(Gram16Regs& r) {
+#pragma unroll
+    for (int u = 0; u < kU16; ++u) {
+        // rhs: two v_pk_fma_f32 with the rating duplicated into a register pair BY HAND.  The compiler's own form reads
+        // the rating through op_sel from (rating, whatever sits in the odd partner register) -- which the allocator
+        // fills with a destination of the loads just issued, and the waitcnt pass then drains every load in flight
+        // (s_waitcnt vmcnt(0)) in front of the MFMA block of every second step.
+        const float hi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+            0, __builtin_bit_cast(int, r.rv[S][u]), 0xE4 /* quad_perm [0,1,2,3]: a plain copy the optimiser cannot fold */, 0xF, 0xF, false));
+        const f32x2 rr = {r.rv[S][u], hi};
+        r.bacc[0] = fma2(rr, r.av[S][u].lo, r.bacc[0]);
+        r.bacc[1] = fma2(rr, r.av[S][u].hi, r.bacc[1]);
+        int ti = 0;
+#pragma unroll
+        for (int e = 0; e < kSets; ++e)
+#pragma unroll
+            for (int f = e; f < kSets; ++f, ++ti)
+                r.acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.av[S][u][e], r.av[S][u][f], r.acc[ti], 0, 0, 0);
+    }
+}
+
+// 4 waves per SIMD (measured with the previous form of the loop: 3 waves 16.3 ms, 4 waves 15.6 ms, 5 waves = 96 VGPRs
+// + 162 spilled dwords 21.1 ms per iteration at the Netflix shape).
+// Why the loop looks the way it does: with ~100 vector instructions around the 40 MFMAs of a step (64-bit address
+// arithmetic per gathered row, clamps and selects per index, register copies between "next" and "current" sets) the
+// four waves of a SIMD needed more issue cycles than the 1280 the MFMAs take, and the Gramian ran at 58 % of the
+// matrix rate whatever the gather was served from.  Now: ~30 vector instructions per step.
+template <bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_als_gram16(AlsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -556,80 +627,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (uint32_t cc = lane; cc < k; cc += 64) a.Y[(size_t) it.seg * k + cc] = 0.f;
         return;
     }
-    f32x4 acc[kTiles16];
-    float bacc[kSets];
+    Gram16Regs r;
 #pragma unroll
-    for (int t = 0; t < kTiles16; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < kSets; ++e) bacc[e] = 0.f;
+    for (int t = 0; t < kTiles16; ++t) r.acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.bacc[0] = r.bacc[1] = f32x2{0.f, 0.f};
 
-    constexpr int U = 4;  // 4-row steps per batch: 16 gathered rows (4 KB) in flight per wave, twice over
-    // Two dependent round trips per batch (index -> factor row), both taken off the critical path:
-    // indices and ratings are fetched two batches ahead, factor rows one batch ahead.  Every load is
-    // UNCONDITIONAL and nothing is masked afterwards: positions past the segment's end (clamped to its
-    // last entry for the index / rating loads) and lanes past column k gather from the all-zero row
-    // X[x_rows], so they add exact zeros.  With the loads inside divergent branches -- or selects on
-    // the loaded rows -- the compiler either drains the memory queue (s_waitcnt vmcnt(0)) in front of
-    // the MFMA block or moves the consumption up to the loads: either way load latency and matrix work
-    // serialise within a wave.
-    const uint32_t last = it.hi - 1;
-    const uint32_t cc = 4 * c < k ? c : 0u;
-    const bool col_ok = 4 * c < k;
-    uint32_t row_n[U];
-    float rv_n[U], rv_c[U];
-    f32x4 av_n[U];
-    auto load_idx = [&](uint32_t q0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + 4 * u + g;
-            const uint32_t r = a.idx[q < last ? q : last];
-            row_n[u] = (col_ok && q < it.hi) ? r : a.x_rows;
-            rv_n[u] = a.val[q < last ? q : last];  // multiplies a zero row when q is past the end
-        }
-    };
-    auto load_rows = [&]() {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            av_n[u] = *(reinterpret_cast<const f32x4*>(a.X + (size_t) row_n[u] * k) + cc);
-            rv_c[u] = rv_n[u];
-        }
-    };
-    load_idx(it.lo);
-    load_rows();
-    load_idx(it.lo + 4 * U);
-    for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 4 * U) {
-        f32x4 av[U];
-        float rv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { av[u] = av_n[u]; rv[u] = rv_c[u]; }
-        load_rows();                // rows of the next batch (their indices arrived during the last one)
-        load_idx(q0 + 8 * U);       // indices of the batch after that
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int ti = 0;
-#pragma unroll
-            for (int e = 0; e < kSets; ++e) {
-                bacc[e] += rv[u] * av[u][e];
-#pragma unroll
-                for (int f = e; f < kSets; ++f, ++ti)
-                    acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], av[u][f], acc[ti], 0, 0, 0);
-            }
-        }
+    const uint32_t len = it.hi - it.lo;
+    const uint32_t* ibase = a.idx + it.lo;
+    const float* vbase = a.val + it.lo;
+    const char* Xb = reinterpret_cast<const char*>(a.X);
+    const uint32_t rowbytes = 4 * k;
+    const bool col_ok = 4 * c < k;                 // lanes past column k gather the zero row
+    const uint32_t lane_off = 16 * c;
+    const uint32_t zero_off = a.x_rows * rowbytes;
+    // step s: MFMAs on set s & 1, factor rows of step s + 1 into the other set, indices of step s + 2 into this one
+    g16_load_idx<0>(r, ibase, 0, g);
+    g16_load_idx<1>(r, ibase, 1, g);
+    g16_load_rows<0>(r, Xb, vbase, 0, g, len, col_ok, rowbytes, lane_off, zero_off);
+    for (uint32_t s = 0;;) {
+        // (sched_barrier: left to itself the scheduler sinks the loads of a step down to their first use, one step later)
+        g16_load_rows<1>(r, Xb, vbase, s + 1, g, len, col_ok, rowbytes, lane_off, zero_off);
+        g16_load_idx<0>(r, ibase, s + 2, g);
+        __builtin_amdgcn_sched_barrier(0);
+        g16_mfma<0>(r);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++s * 16 >= len) break;
+        g16_load_rows<0>(r, Xb, vbase, s + 1, g, len, col_ok, rowbytes, lane_off, zero_off);
+        g16_load_idx<1>(r, ibase, s + 2, g);
+        __builtin_amdgcn_sched_barrier(0);
+        g16_mfma<1>(r);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++s * 16 >= len) break;
     }
     if (it.slot >= 0) {  // chunk of a long segment: park the raw accumulators, the reducer finishes
         float* w = a.ws + (size_t) it.slot * slot_floats<2>();
 #pragma unroll
         for (int t = 0; t < kTiles16; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[t * 256 + r * 64 + lane] = acc[t][r];
+            for (int q = 0; q < 4; ++q) w[t * 256 + q * 64 + lane] = r.acc[t][q];
 #pragma unroll
-        for (int e = 0; e < kSets; ++e) w[kTiles16 * 256 + e * 64 + lane] = bacc[e];
+        for (int e = 0; e < kSets; ++e) w[kTiles16 * 256 + e * 64 + lane] = r.bacc[e >> 1][e & 1];
         return;
     }
-    stage_tiles16(acc, bacc, lds);
-    factor_solve<2>(lds, a, it.seg);
+    float bacc[kSets] = {r.bacc[0].x, r.bacc[0].y, r.bacc[1].x, r.bacc[1].y};
+    stage_tiles16(r.acc, bacc, lds);
+    factor_solve<2, FULL>(lds, a, it.seg);
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63;
@@ -651,7 +696,7 @@ __global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
         for (int e = 0; e < kSets; ++e) bacc[e] += w[kTiles16 * 256 + e * 64 + lane];
     }
     stage_tiles16(acc, bacc, lds);
-    factor_solve<2>(lds, a, rd.seg);
+    factor_solve<2, FULL>(lds, a, rd.seg);
 }
 
 int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
@@ -659,12 +704,14 @@ int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipS
     AlsArgs a = base;
     if (nitems) {
         a.count = nitems;
-        hipLaunchKernelGGL(k_als_gram16, dim3(nitems), dim3(64), lds_bytes, st, a);
+        if (a.k == 64) hipLaunchKernelGGL(k_als_gram16<true>, dim3(nitems), dim3(64), lds_bytes, st, a);
+        else hipLaunchKernelGGL(k_als_gram16<false>, dim3(nitems), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     if (nreduces) {
         a.count = nreduces;
-        hipLaunchKernelGGL(k_als_reduce16, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        if (a.k == 64) hipLaunchKernelGGL(k_als_reduce16<true>, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        else hipLaunchKernelGGL(k_als_reduce16<false>, dim3(nreduces), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     return MFX_OK;
@@ -697,7 +744,9 @@ int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipS
 
 int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
     const uint32_t nt = (a.k + 31) / 32;
-    if (a.k > 32 && a.k <= 64 && a.k % 4 == 0) return launch_half_16(a, nitems, nreduces, st);  // 16-byte aligned factor rows
+    // 16-byte aligned factor rows; k_als_gram16 forms 32-bit byte offsets into X with a 24-bit multiply
+    if (a.k > 32 && a.k <= 64 && a.k % 4 == 0 && a.x_rows < (1u << 24) && ((uint64_t) a.x_rows + 1) * a.k * 4 < (1ull << 32))
+        return launch_half_16(a, nitems, nreduces, st);
     switch (nt) {
         case 1: return launch_half_nt<1>(a, nitems, nreduces, st);
         case 2: return launch_half_nt<2>(a, nitems, nreduces, st);
@@ -708,6 +757,7 @@ int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, hipStream_
 }
 
 constexpr uint32_t kAlsChunk = 1024;  // gathered rows per wavefront before a segment is split
+constexpr uint32_t kAlsPad = 64;      // entries behind the index / value arrays (see AlsHalf::build)
 
 }  // namespace
 
@@ -746,8 +796,14 @@ int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, uint32_t G, const uint32_t* pt
     nreduces = (uint32_t) rd.size();
     nslots = slots;
     MFX_TRY(ptr.alloc(hp.size())); MFX_TRY(ptr.upload(hp.data(), hp.size(), MFX_HOST, st));
-    MFX_TRY(idx.alloc(nnz ? nnz : 1)); MFX_TRY(idx.upload(idx_in, nnz, space, st));
-    MFX_TRY(val.alloc(nnz ? nnz : 1)); MFX_TRY(val.upload(val_in, nnz, space, st));
+    // kAlsPad extra entries each: entry nnz is (G, 0) = "the all-zero row of X, rating 0", the stand-in of k_als_gram<NT>
+    // for positions past a segment's end; the rest is zero padding that k_als_gram16 may read (and ignore) past the
+    // last segment
+    MFX_TRY(idx.alloc(nnz + kAlsPad)); MFX_TRY(idx.upload(idx_in, nnz, space, st));
+    MFX_TRY(val.alloc(nnz + kAlsPad)); MFX_TRY(val.upload(val_in, nnz, space, st));
+    MFX_HIP(hipMemsetAsync(idx.get() + nnz, 0, sizeof(uint32_t) * kAlsPad, st));
+    MFX_HIP(hipMemsetAsync(val.get() + nnz, 0, sizeof(float) * kAlsPad, st));
+    MFX_HIP(hipMemcpyAsync(idx.get() + nnz, &G, sizeof(uint32_t), hipMemcpyHostToDevice, st));
     MFX_TRY(items.alloc(nitems ? nitems : 1)); MFX_TRY(items.upload(it.data(), nitems, MFX_HOST, st));
     MFX_TRY(reduces.alloc(nreduces ? nreduces : 1)); MFX_TRY(reduces.upload(rd.data(), nreduces, MFX_HOST, st));
     MFX_HIP(hipStreamSynchronize(st));
@@ -760,7 +816,7 @@ int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y,
                     uint32_t* spd_fail, hipStream_t st) {
     AlsArgs a{};
     a.items = h.items.get(); a.reduces = h.reduces.get(); a.idx = h.idx.get(); a.val = h.val.get();
-    a.X = X; a.x_rows = x_rows; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
+    a.X = X; a.x_rows = x_rows; a.sentinel = (uint32_t) h.nnz; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
     return launch_half(a, h.nitems, h.nreduces, st);
 }
 
@@ -977,16 +1033,18 @@ int als_gramian_op(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const floa
     OpStream os;
     MFX_HIP(hipStreamCreateWithFlags(&os.st, hipStreamNonBlocking));
     DevBuf<uint32_t> didx, fail_cnt; DevBuf<float> dval, dX, dY, dA; DevBuf<AlsItem> ditem;
-    MFX_TRY(didx.alloc(cnt)); MFX_TRY(didx.upload(idx, cnt, MFX_HOST, os.st));
+    const uint32_t zrow = (uint32_t) nrows_x;
+    MFX_TRY(didx.alloc_zero(cnt + kAlsPad, os.st)); MFX_TRY(didx.upload(idx, cnt, MFX_HOST, os.st));
+    MFX_HIP(hipMemcpyAsync(didx.get() + cnt, &zrow, sizeof(uint32_t), hipMemcpyHostToDevice, os.st));
     MFX_TRY(check_index_range(didx.get(), (uint64_t) cnt, (uint32_t) nrows_x, "ALS gather index", os.st));
-    MFX_TRY(dval.alloc_zero(cnt, os.st));
+    MFX_TRY(dval.alloc_zero(cnt + kAlsPad, os.st));
     MFX_TRY(dX.alloc_zero(((size_t) nrows_x + 1) * k, os.st)); MFX_TRY(dX.upload(X, (size_t) nrows_x * k, MFX_HOST, os.st));
     MFX_TRY(dY.alloc_zero(k, os.st)); MFX_TRY(dA.alloc_zero((size_t) k * k, os.st));
     MFX_TRY(fail_cnt.alloc_zero(1, os.st));
     AlsItem it{0, 0, (uint32_t) cnt, -1};
     MFX_TRY(ditem.alloc(1)); MFX_TRY(ditem.upload(&it, 1, MFX_HOST, os.st));
     AlsArgs a{};
-    a.items = ditem.get(); a.idx = didx.get(); a.val = dval.get(); a.X = dX.get(); a.x_rows = (uint32_t) nrows_x; a.Y = dY.get();
+    a.items = ditem.get(); a.idx = didx.get(); a.val = dval.get(); a.X = dX.get(); a.x_rows = (uint32_t) nrows_x; a.sentinel = (uint32_t) cnt; a.Y = dY.get();
     a.k = (uint32_t) k; a.lambda = 0.f; a.spd_fail = fail_cnt.get(); a.gram_out = dA.get();
     MFX_TRY(launch_half(a, 1, 0, os.st));
     MFX_HIP(hipMemcpyAsync(A, dA.get(), sizeof(float) * k * k, hipMemcpyDeviceToHost, os.st));
