@@ -756,7 +756,7 @@ int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, hipStream_
     }
 }
 
-constexpr uint32_t kAlsChunk = 1024;  // gathered rows per wavefront before a segment is split
+constexpr uint32_t kAlsChunk = 2048;  // gathered rows per wavefront before a segment is split
 constexpr uint32_t kAlsPad = 64;      // entries behind the index / value arrays (see AlsHalf::build)
 
 }  // namespace

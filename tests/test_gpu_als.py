@@ -123,7 +123,7 @@ def test_als_as_written_half_vs_oracle_bit_exact(mfx, orc, k):
 def test_als_medium_vs_oracle(mfx, orc, k):
     """Rows longer than one chunk (split Gramians + reducer), k across all tile counts."""
     d = mfx.dataset.synth_ratings(3000, 400, 150_000, seed=31 + k, skew=1.1, test_frac=0.01, empty_row_frac=0.02)
-    assert np.diff(d.csc_col_ptr.astype(np.int64)).max() > 1024
+    assert np.diff(d.csc_col_ptr.astype(np.int64)).max() > 2048  # kAlsChunk (als_solver.hip)
     H0 = mfx.initial_col(d.cols, k)
     Wr, Hr, rmse_ref, _ = orc.als(d, H0, k, 0.05, 2, orc.max_threads())
     s = mfx.AlsSolver(d, mfx.test_data_of(d), _p(mfx, k, 0.05, 2))
