@@ -181,3 +181,55 @@ def test_sharded_als_multi_rank_loopback(mfx, orc, nranks, k):
         assert np.array_equal(W.view(np.uint32), W1.view(np.uint32)) and np.array_equal(H.view(np.uint32), H1.view(np.uint32))
         assert np.all(np.abs(np.array(rm) - rmse_ref) < 1e-4)
         assert relerr(W, Wr) < 5e-3 and relerr(H, Hr) < 5e-3
+
+
+def _solve_f64(ptr, idx, val, X, k, lam):
+    out = np.zeros((ptr.shape[0] - 1, k))
+    for s in range(ptr.shape[0] - 1):
+        lo, hi = int(ptr[s]), int(ptr[s + 1])
+        if hi == lo:
+            continue
+        x = X[idx[lo:hi]].astype(np.float64)
+        out[s] = np.linalg.solve(x.T @ x + lam * np.eye(k), x.T @ val[lo:hi].astype(np.float64))
+    return out
+
+
+@pytest.mark.parametrize("k", [36, 64])
+def test_als_half_segment_ends_and_padding(mfx, k):
+    """k_als_gram16 reads its index / rating streams in whole 16-entry steps, two steps ahead: segments of every
+    length mod 16 (1 .. 40 entries, an empty one, one longer than a chunk), the last one ending exactly at the end
+    of the arrays, against a float64 solve -- nothing read past a segment's end may leak into its system."""
+    rng = np.random.default_rng(5 + k)
+    lens = list(range(1, 41)) + [0, 17, 2049 + 13, 3, 16]
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    nnz, G = int(ptr[-1]), 500
+    idx = rng.integers(0, G, nnz).astype(np.uint32)
+    val = rng.uniform(1.0, 5.0, nnz).astype(np.float32)
+    X = rng.uniform(-1.0, 1.0, (G, k)).astype(np.float32)
+    Y = mfx.als_half(ptr, idx, val, X, k, 0.05)
+    ref = _solve_f64(ptr, idx, val, X, k, 0.05)
+    assert np.array_equal(Y[40], np.zeros(k, np.float32))  # the empty segment (src/ALS.cpp:151-157)
+    # short segments are underdetermined (lambda alone makes them solvable): compare the RESIDUAL of the normal
+    # equations as well as the solution
+    assert relerr(Y, ref) < 2e-3
+    for s in (0, 15, 16, 39, 41, 42, 44):
+        lo, hi = int(ptr[s]), int(ptr[s + 1])
+        x = X[idx[lo:hi]].astype(np.float64)
+        A, b = x.T @ x + 0.05 * np.eye(k), x.T @ val[lo:hi].astype(np.float64)
+        assert np.max(np.abs(A @ Y[s].astype(np.float64) - b)) < 1e-3 * max(1.0, np.max(np.abs(b)))
+
+
+def test_als_half_gather_table_past_the_32_bit_offsets(mfx):
+    """k = 36 over a gather table of 2^24 + 5 rows: k_als_gram16 forms 32-bit byte offsets with a 24-bit multiply, so
+    this shape must take the generic 32x32x2 kernel (launch_half) -- and gather the LAST rows correctly."""
+    k, G = 36, (1 << 24) + 5
+    rng = np.random.default_rng(77)
+    hot = np.array([0, 1, 4095, (1 << 24) - 1, 1 << 24, G - 1, G - 2, 123456], np.uint32)
+    X = np.zeros((G, k), np.float32)
+    X[hot] = rng.uniform(-1.0, 1.0, (hot.size, k)).astype(np.float32)
+    lens = [40, 7, 100]
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    idx = hot[rng.integers(0, hot.size, int(ptr[-1]))].astype(np.uint32)
+    val = rng.uniform(1.0, 5.0, int(ptr[-1])).astype(np.float32)
+    Y = mfx.als_half(ptr, idx, val, X, k, 0.05)
+    assert relerr(Y, _solve_f64(ptr, idx, val, X, k, 0.05)) < 2e-3
