@@ -219,7 +219,8 @@ __device__ void chol_blocked(float* __restrict__ L, bool& spd_ok) {
 }
 
 // LDS image -> + lambda, Cholesky, two triangular solves, Y[seg] <- solution.
-// FULL: k == KP known at compile time (the k = 64 kernels: no per-column `i < k` branches, no `lane < k` masks).
+// FULL: k == KP known at compile time (k = 64: no per-column `i < k` branches, no `lane < k` masks; user half at the
+// Netflix shape 8.24 -> 7.89 ms)
 template <int NT, bool FULL = false>
 __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     constexpr int KP = 32 * NT;
@@ -609,14 +610,18 @@ __device__ __forceinline__ void g16_mfma(Gram16Regs& r) {
     }
 }
 
-// 4 waves per SIMD (measured with the previous form of the loop: 3 waves 16.3 ms, 4 waves 15.6 ms, 5 waves = 96 VGPRs
-// + 162 spilled dwords 21.1 ms per iteration at the Netflix shape).
 // Why the loop looks the way it does: with ~100 vector instructions around the 40 MFMAs of a step (64-bit address
-// arithmetic per gathered row, clamps and selects per index, register copies between "next" and "current" sets) the
-// four waves of a SIMD needed more issue cycles than the 1280 the MFMAs take, and the Gramian ran at 58 % of the
-// matrix rate whatever the gather was served from.  Now: ~30 vector instructions per step.
-template <bool FULL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_als_gram16(AlsArgs a) {
+// arithmetic per gathered row, clamps and selects per index, register copies between "next" and "current" sets, a
+// flat_load born from a select between two addresses) the loop was replaced by this explicit two-set pipeline:
+// ~45 vector instructions per step.  tools/ubench_mfma32.hip replays it on L1-resident data: 130 TF of the 157 TF
+// fp32 matrix peak at 2.4 GHz; inside the solver (2.2 GHz under load) the Gramian alone runs at 62 % of the matrix
+// rate whether the gather is served from HBM, L2 or L1 -- the rest of a half-sweep is the per-system tail.
+// WAVES per SIMD: a launch whose items are long (the item half: 2048-row chunks, hardly any tails) is fastest with
+// TWO waves per SIMD (5.42 -> 4.91 ms at the Netflix shape), one dominated by per-system tails (the user half, 206
+// entries per system) wants the latency hiding of three or four (7.9 ms; 9.2 ms at two).  Three = 168 VGPRs, no
+// spills; four = 128 VGPRs + 18 spilled dwords, same time.
+template <int WAVES, bool FULL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_als_gram16(AlsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const uint32_t item = blockIdx.x;
@@ -674,7 +679,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     factor_solve<2, FULL>(lds, a, it.seg);
 }
 
-template <bool FULL>
 __global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63;
@@ -696,22 +700,25 @@ __global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
         for (int e = 0; e < kSets; ++e) bacc[e] += w[kTiles16 * 256 + e * 64 + lane];
     }
     stage_tiles16(acc, bacc, lds);
-    factor_solve<2, FULL>(lds, a, rd.seg);
+    factor_solve<2>(lds, a, rd.seg);
 }
 
-int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
+int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, uint64_t nnz, hipStream_t st) {
     const size_t lds_bytes = ((size_t) roff_host(64) + 64) * sizeof(float);
     AlsArgs a = base;
     if (nitems) {
         a.count = nitems;
-        if (a.k == 64) hipLaunchKernelGGL(k_als_gram16<true>, dim3(nitems), dim3(64), lds_bytes, st, a);
-        else hipLaunchKernelGGL(k_als_gram16<false>, dim3(nitems), dim3(64), lds_bytes, st, a);
+        // mean entries per work item: long items -> two waves per SIMD, tail-dominated launches -> three
+        const bool longs = nnz / nitems >= 1024, full = a.k == 64;
+        if (longs && full) hipLaunchKernelGGL((k_als_gram16<2, true>), dim3(nitems), dim3(64), lds_bytes, st, a);
+        else if (longs) hipLaunchKernelGGL((k_als_gram16<2, false>), dim3(nitems), dim3(64), lds_bytes, st, a);
+        else if (full) hipLaunchKernelGGL((k_als_gram16<3, true>), dim3(nitems), dim3(64), lds_bytes, st, a);
+        else hipLaunchKernelGGL((k_als_gram16<3, false>), dim3(nitems), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     if (nreduces) {
         a.count = nreduces;
-        if (a.k == 64) hipLaunchKernelGGL(k_als_reduce16<true>, dim3(nreduces), dim3(64), lds_bytes, st, a);
-        else hipLaunchKernelGGL(k_als_reduce16<false>, dim3(nreduces), dim3(64), lds_bytes, st, a);
+        hipLaunchKernelGGL(k_als_reduce16, dim3(nreduces), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     return MFX_OK;
@@ -742,11 +749,11 @@ int launch_half_nt(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, hipS
     return MFX_OK;
 }
 
-int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, hipStream_t st) {
+int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, uint64_t nnz, hipStream_t st) {
     const uint32_t nt = (a.k + 31) / 32;
     // 16-byte aligned factor rows; k_als_gram16 forms 32-bit byte offsets into X with a 24-bit multiply
     if (a.k > 32 && a.k <= 64 && a.k % 4 == 0 && a.x_rows < (1u << 24) && ((uint64_t) a.x_rows + 1) * a.k * 4 < (1ull << 32))
-        return launch_half_16(a, nitems, nreduces, st);
+        return launch_half_16(a, nitems, nreduces, nnz, st);
     switch (nt) {
         case 1: return launch_half_nt<1>(a, nitems, nreduces, st);
         case 2: return launch_half_nt<2>(a, nitems, nreduces, st);
@@ -817,7 +824,7 @@ int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y,
     AlsArgs a{};
     a.items = h.items.get(); a.reduces = h.reduces.get(); a.idx = h.idx.get(); a.val = h.val.get();
     a.X = X; a.x_rows = x_rows; a.sentinel = (uint32_t) h.nnz; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
-    return launch_half(a, h.nitems, h.nreduces, st);
+    return launch_half(a, h.nitems, h.nreduces, h.nnz, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1046,7 +1053,7 @@ int als_gramian_op(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const floa
     AlsArgs a{};
     a.items = ditem.get(); a.idx = didx.get(); a.val = dval.get(); a.X = dX.get(); a.x_rows = (uint32_t) nrows_x; a.sentinel = (uint32_t) cnt; a.Y = dY.get();
     a.k = (uint32_t) k; a.lambda = 0.f; a.spd_fail = fail_cnt.get(); a.gram_out = dA.get();
-    MFX_TRY(launch_half(a, 1, 0, os.st));
+    MFX_TRY(launch_half(a, 1, 0, (uint64_t) cnt, os.st));
     MFX_HIP(hipMemcpyAsync(A, dA.get(), sizeof(float) * k * k, hipMemcpyDeviceToHost, os.st));
     MFX_HIP(hipStreamSynchronize(os.st));
     return MFX_OK;
