@@ -551,12 +551,13 @@ __device__ __forceinline__ void stage_tiles16(f32x4 (&acc)[kTiles16], float (&ba
     }
 }
 
-// Pipeline state of k_als_gram16: two register sets, used alternately by consecutive 16-row steps (no copies).
+// Pipeline state of k_als_gram16: D register sets, used in turn by consecutive 16-row steps (no copies).
 constexpr int kU16 = 4;  // 4-row MFMA groups per step: 16 gathered rows (4 KB) per set
+template <int D>
 struct Gram16Regs {
-    uint32_t ix[2][kU16];  // gathered row indices           (stage 0: loaded two steps ahead of their MFMAs)
-    f32x4 av[2][kU16];     // gathered factor-row quarters   (stage 1: one step ahead)
-    float rv[2][kU16];     // ratings                        (stage 1)
+    uint32_t ix[D][kU16];  // gathered row indices           (stage 0: loaded D steps ahead of their MFMAs)
+    f32x4 av[D][kU16];     // gathered factor-row quarters   (stage 1: D - 1 steps ahead)
+    float rv[D][kU16];     // ratings                        (stage 1)
     f32x4 acc[kTiles16];
     f32x2 bacc[2];         // rhs partial sums of column sets (0, 1) and (2, 3)
 };
@@ -567,13 +568,13 @@ struct Gram16Regs {
 // vector unit.  Positions past the item's end read on into the next segment's entries (or the arrays' zero padding,
 // AlsHalf::build); their ROW OFFSET is replaced by the all-zero row X[x_rows], so they add exact zeros (a rating
 // read from past the end multiplies that zero row).
-template <int S>
-__device__ __forceinline__ void g16_load_idx(Gram16Regs& r, const uint32_t* __restrict__ ibase, uint32_t s, uint32_t g) {
+template <int D, int S>
+__device__ __forceinline__ void g16_load_idx(Gram16Regs<D>& r, const uint32_t* __restrict__ ibase, uint32_t s, uint32_t g) {
 #pragma unroll
     for (int u = 0; u < kU16; ++u) r.ix[S][u] = ibase[s * 16 + 4 * u + g];
 }
-template <int S>
-__device__ __forceinline__ void g16_load_rows(Gram16Regs& r, const char* __restrict__ Xb, const float* __restrict__ vbase,
+template <int D, int S>
+__device__ __forceinline__ void g16_load_rows(Gram16Regs<D>& r, const char* __restrict__ Xb, const float* __restrict__ vbase,
                                               uint32_t s, uint32_t g, uint32_t len, bool col_ok, uint32_t rowbytes,
                                               uint32_t lane_off, uint32_t zero_off) {
 #pragma unroll
@@ -588,8 +589,8 @@ __device__ __forceinline__ void g16_load_rows(Gram16Regs& r, const char* __restr
         r.rv[S][u] = vbase[s * 16 + 4 * u + g];
     }
 }
-template <int S>
-__device__ __forceinline__ void g16_mfma(Gram16Regs& r) {
+template <int D, int S>
+__device__ __forceinline__ void g16_mfma(Gram16Regs<D>& r) {
 #pragma unroll
     for (int u = 0; u < kU16; ++u) {
         // rhs: two v_pk_fma_f32 with the rating duplicated into a register pair BY HAND.  The compiler's own form reads
@@ -609,6 +610,38 @@ __device__ __forceinline__ void g16_mfma(Gram16Regs& r) {
                 r.acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(r.av[S][u][e], r.av[S][u][f], r.acc[ti], 0, 0, 0);
     }
 }
+struct Gram16Ctx {  // loop-invariant operands of the stages
+    const uint32_t* ibase; const float* vbase; const char* Xb;
+    uint32_t g, len, rowbytes, lane_off, zero_off;
+    bool col_ok;
+};
+// Steps s, s + 1, ... on sets U, U + 1, ... D - 1: MFMAs of step s on set U, the factor rows of step s + D - 1 into the
+// set the previous step has just released, the indices of step s + D into this step's own (already consumed) slots.
+// True when the item is finished.  (sched_barrier: left to itself the scheduler sinks the loads of a step down to
+// their first use, D - 1 steps later.)
+template <int D, int U>
+__device__ __forceinline__ bool g16_steps(Gram16Regs<D>& r, const Gram16Ctx& c, uint32_t& s) {
+    if constexpr (U < D) {
+        g16_load_rows<D, (U + D - 1) % D>(r, c.Xb, c.vbase, s + D - 1, c.g, c.len, c.col_ok, c.rowbytes, c.lane_off, c.zero_off);
+        g16_load_idx<D, U>(r, c.ibase, s + D, c.g);
+        __builtin_amdgcn_sched_barrier(0);
+        g16_mfma<D, U>(r);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++s * 16 >= c.len) return true;
+        return g16_steps<D, U + 1>(r, c, s);
+    } else {
+        return false;
+    }
+}
+template <int D, int U>
+__device__ __forceinline__ void g16_prologue(Gram16Regs<D>& r, const Gram16Ctx& c) {
+    if constexpr (U < D) {
+        g16_load_idx<D, U>(r, c.ibase, U, c.g);
+        g16_prologue<D, U + 1>(r, c);
+        if constexpr (U + 1 < D)  // (after ALL index loads are in flight)
+            g16_load_rows<D, U>(r, c.Xb, c.vbase, U, c.g, c.len, c.col_ok, c.rowbytes, c.lane_off, c.zero_off);
+    }
+}
 
 // Why the loop looks the way it does: with ~100 vector instructions around the 40 MFMAs of a step (64-bit address
 // arithmetic per gathered row, clamps and selects per index, register copies between "next" and "current" sets, a
@@ -620,7 +653,7 @@ __device__ __forceinline__ void g16_mfma(Gram16Regs& r) {
 // TWO waves per SIMD (5.42 -> 4.91 ms at the Netflix shape), one dominated by per-system tails (the user half, 206
 // entries per system) wants the latency hiding of three or four (7.9 ms; 9.2 ms at two).  Three = 168 VGPRs, no
 // spills; four = 128 VGPRs + 18 spilled dwords, same time.
-template <int WAVES, bool FULL>
+template <int WAVES, int D, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_als_gram16(AlsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -632,38 +665,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         for (uint32_t cc = lane; cc < k; cc += 64) a.Y[(size_t) it.seg * k + cc] = 0.f;
         return;
     }
-    Gram16Regs r;
+    Gram16Regs<D> r;
 #pragma unroll
     for (int t = 0; t < kTiles16; ++t) r.acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     r.bacc[0] = r.bacc[1] = f32x2{0.f, 0.f};
 
-    const uint32_t len = it.hi - it.lo;
-    const uint32_t* ibase = a.idx + it.lo;
-    const float* vbase = a.val + it.lo;
-    const char* Xb = reinterpret_cast<const char*>(a.X);
-    const uint32_t rowbytes = 4 * k;
-    const bool col_ok = 4 * c < k;                 // lanes past column k gather the zero row
-    const uint32_t lane_off = 16 * c;
-    const uint32_t zero_off = a.x_rows * rowbytes;
-    // step s: MFMAs on set s & 1, factor rows of step s + 1 into the other set, indices of step s + 2 into this one
-    g16_load_idx<0>(r, ibase, 0, g);
-    g16_load_idx<1>(r, ibase, 1, g);
-    g16_load_rows<0>(r, Xb, vbase, 0, g, len, col_ok, rowbytes, lane_off, zero_off);
-    for (uint32_t s = 0;;) {
-        // (sched_barrier: left to itself the scheduler sinks the loads of a step down to their first use, one step later)
-        g16_load_rows<1>(r, Xb, vbase, s + 1, g, len, col_ok, rowbytes, lane_off, zero_off);
-        g16_load_idx<0>(r, ibase, s + 2, g);
-        __builtin_amdgcn_sched_barrier(0);
-        g16_mfma<0>(r);
-        __builtin_amdgcn_sched_barrier(0);
-        if (++s * 16 >= len) break;
-        g16_load_rows<0>(r, Xb, vbase, s + 1, g, len, col_ok, rowbytes, lane_off, zero_off);
-        g16_load_idx<1>(r, ibase, s + 2, g);
-        __builtin_amdgcn_sched_barrier(0);
-        g16_mfma<1>(r);
-        __builtin_amdgcn_sched_barrier(0);
-        if (++s * 16 >= len) break;
-    }
+    Gram16Ctx cx;
+    cx.len = it.hi - it.lo;
+    cx.ibase = a.idx + it.lo;
+    cx.vbase = a.val + it.lo;
+    cx.Xb = reinterpret_cast<const char*>(a.X);
+    cx.rowbytes = 4 * k;
+    cx.col_ok = 4 * c < k;                 // lanes past column k gather the zero row
+    cx.lane_off = 16 * c;
+    cx.zero_off = a.x_rows * cx.rowbytes;
+    cx.g = g;
+    g16_prologue<D, 0>(r, cx);
+    for (uint32_t s = 0;;)
+        if (g16_steps<D, 0>(r, cx, s)) break;
     if (it.slot >= 0) {  // chunk of a long segment: park the raw accumulators, the reducer finishes
         float* w = a.ws + (size_t) it.slot * slot_floats<2>();
 #pragma unroll
@@ -703,6 +722,15 @@ __global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
     factor_solve<2>(lds, a, rd.seg);
 }
 
+// (waves per SIMD, pipeline depth) of k_als_gram16 for launches of long items / of tail-dominated items.  Depth:
+// measured at the Netflix shape, item half: (2 waves, depth 2) 4.90 ms, (2, 4) 4.93, (2, 6) 4.94, (3, 4) 5.09 -- the
+// gather of 25 GB of 256-byte rows from a 123 MB table runs at 5.2 TB/s either way.
+#ifndef MFX_G16_WL
+#define MFX_G16_WL 2
+#define MFX_G16_DL 2
+#define MFX_G16_WS 3
+#define MFX_G16_DS 2
+#endif
 int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, uint64_t nnz, hipStream_t st) {
     const size_t lds_bytes = ((size_t) roff_host(64) + 64) * sizeof(float);
     AlsArgs a = base;
@@ -710,10 +738,10 @@ int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, uint
         a.count = nitems;
         // mean entries per work item: long items -> two waves per SIMD, tail-dominated launches -> three
         const bool longs = nnz / nitems >= 1024, full = a.k == 64;
-        if (longs && full) hipLaunchKernelGGL((k_als_gram16<2, true>), dim3(nitems), dim3(64), lds_bytes, st, a);
-        else if (longs) hipLaunchKernelGGL((k_als_gram16<2, false>), dim3(nitems), dim3(64), lds_bytes, st, a);
-        else if (full) hipLaunchKernelGGL((k_als_gram16<3, true>), dim3(nitems), dim3(64), lds_bytes, st, a);
-        else hipLaunchKernelGGL((k_als_gram16<3, false>), dim3(nitems), dim3(64), lds_bytes, st, a);
+        if (longs && full) hipLaunchKernelGGL((k_als_gram16<MFX_G16_WL, MFX_G16_DL, true>), dim3(nitems), dim3(64), lds_bytes, st, a);
+        else if (longs) hipLaunchKernelGGL((k_als_gram16<MFX_G16_WL, MFX_G16_DL, false>), dim3(nitems), dim3(64), lds_bytes, st, a);
+        else if (full) hipLaunchKernelGGL((k_als_gram16<MFX_G16_WS, MFX_G16_DS, true>), dim3(nitems), dim3(64), lds_bytes, st, a);
+        else hipLaunchKernelGGL((k_als_gram16<MFX_G16_WS, MFX_G16_DS, false>), dim3(nitems), dim3(64), lds_bytes, st, a);
         MFX_HIP(hipGetLastError());
     }
     if (nreduces) {
@@ -764,7 +792,7 @@ int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, uint64_t n
 }
 
 constexpr uint32_t kAlsChunk = 2048;  // gathered rows per wavefront before a segment is split
-constexpr uint32_t kAlsPad = 64;      // entries behind the index / value arrays (see AlsHalf::build)
+constexpr uint32_t kAlsPad = 128;     // entries behind the index / value arrays (see AlsHalf::build)
 
 }  // namespace
 
