@@ -236,7 +236,8 @@ int mfx_update_rating(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint
  * calrmse (src/tools.cpp:235-248): fp32 products, fp64 sums. */
 int mfx_test_rmse(const mfx_coo* T, const float* W, const float* H, int64_t rows, int64_t cols,
                   int64_t k, int ifALS, double* rmse_out, int device);
-/* Mt_byM_multiply_k (cuda_src/ALS_CUDA.cu:65-79): A[k][k] = sum over idx of x x^T. */
+/* Mt_byM_multiply_k (cuda_src/ALS_CUDA.cu:65-79): A[k][k] = sum over idx of x x^T (cnt <= 2048: one wavefront's
+ * share of a segment; the half-sweep below splits longer segments and adds the pieces in a fixed order). */
 int mfx_als_gramian(int64_t cnt, const uint32_t* idx, int64_t nrows_x, const float* X, int64_t k,
                     float* A, int device);
 /* inverseMatrix_CholeskyMethod_k (cuda_src/ALS_CUDA.cu:41-62) == choldc1 / choldcsl /
