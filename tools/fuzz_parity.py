@@ -68,7 +68,7 @@ for case in range(a.cases):
     t = p.maxiter
     if skip:
         continue
-    tag = f"case {case}: {rows}x{cols} nnz={d.nnz} k={k} lam={lam} T={T} t={t} {lay} pr={p.panel_rows} tile={p.tile} tps={p.tiles_per_span} wg={p.wg_waves}"
+    tag = f"case {case}: {rows}x{cols} nnz={d.nnz} k={k} lam={lam} T={T} t={t} {lay} pr={p.panel_rows} tps={p.tiles_per_span} wg={p.wg_waves}"
     try:
         W0 = mfx.initial_col(k, d.rows)
         Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, T, orc.max_threads() if a.big else 2)
