@@ -164,7 +164,8 @@ __device__ __forceinline__ void chol_panel_pass(float* __restrict__ L, int J, in
         }
 #pragma unroll
         for (int q = i & ~3; q < i; ++q) s01.x = __builtin_fmaf(pivrow[q], r2[q / 2][q & 1], s01.x);
-        const float sum = r2[i / 2][i & 1] - ((s01.x + s01.y) + (s23.x + s23.y));
+        const f32x2 s4 = s01 + s23;  // one v_pk_add_f32, then the two halves
+        const float sum = r2[i / 2][i & 1] - (s4.x + s4.y);
         float lji;
         if constexpr (DIAG) {
             const float piv = rl(sum, i);  // lane i < 32 owns the diagonal entry
@@ -275,7 +276,6 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
         // Lane i's own product pivot * rs is the diagonal entry sqrt(pivot) to within an ulp, so there is no select
         // between "diagonal" and "below", no correctly rounded sqrt and no IEEE division in the loop (they were 21 of
         // the ~45 VALU instructions of a step; the solves below take 1 / L[i][i] once, in parallel).
-        bool spd_ok = true;
 #pragma unroll
         for (int i = 0; i < KP; ++i) {
             if (i < k) {  // wave-uniform
@@ -288,28 +288,33 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
                 }
 #pragma unroll
                 for (int q = i & ~3; q < i; ++q) s01.x = __builtin_fmaf(rl(r2[q / 2][q & 1], i), r2[q / 2][q & 1], s01.x);
-                const float sum = r2[i / 2][i & 1] - ((s01.x + s01.y) + (s23.x + s23.y));
+                const f32x2 s4 = s01 + s23;  // one v_pk_add_f32, then the two halves
+        const float sum = r2[i / 2][i & 1] - (s4.x + s4.y);
                 const float piv = rl(sum, i);
-                spd_ok = spd_ok && piv > 0.f;  // wave-uniform; NaN fails the comparison as well
-                const float lji = sum * rsqrt_nr(piv);
+                // v_rsq_f32 as it comes (1 ulp): a column of L scaled by (1 + 1e-7) perturbs L L^T like one more fp32
+                // rounding of A's entries; a Newton step here costs four more VALU instructions per column
+                const float lji = sum * __builtin_amdgcn_rsqf(piv);
                 r2[i / 2][i & 1] = lji;  // lanes j < i: a register slot (column i > j) they never read
                 if ((int) lane >= i && (int) lane < KP) L[roff((int) lane) + i] = lji;
             }
         }
-        if (lane == 0 && !spd_ok) atomicAdd(a.spd_fail, 1u);  // one count per system (the k > 64 form counts pivots)
         __syncthreads();
         // Triangular solves on the UNSCALED unknowns: lane i carries z_i * L[i][i] until the very end, so a step is
         // scale (one multiply for all lanes), broadcast (v_readlane), update (one masked fma) -- no per-step select of
         // the finished component.  The forward pass takes L[lane][i] from the lane's registers, the backward pass reads
         // row i of L from LDS at a compile-time offset (lane-strided, conflict-free).  Rows k .. KP-1 are identity rows
         // with a zero rhs: their updates add exact zeros.
+        // (the lane masks of the solves are FLOAT compares on purpose: as integer compares they are the store masks
+        // of the factorisation loop above, get computed there, and 128 of them are kept alive across it in VGPR lanes)
         float z = lane < (uint32_t) k ? bv[lane] : 0.f;
         const float rp = lane < (uint32_t) k ? rcp_nr(L[roff((int) lane) + lane]) : 0.f;
+        float lanef = (float) lane;
+        asm volatile("" : "+v"(lanef));  // (opaque: otherwise the compare is folded back to the integer one)
 #pragma unroll
         for (int i = 0; i < KP; ++i) {  // forward: L z = b
             if (i < k) {
                 const float zi = rl(z * rp, i);
-                z = (int) lane > i ? __builtin_fmaf(-r2[i / 2][i & 1], zi, z) : z;
+                z = lanef > (float) i ? __builtin_fmaf(-r2[i / 2][i & 1], zi, z) : z;
             }
         }
         z *= rp;  // = the solution of L z = b; the backward pass carries y_i * L[i][i] the same way
@@ -318,11 +323,16 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
             if (i < k) {
                 const float yi = rl(z * rp, i);
                 const float lij = L[roff(i) + (int) lane];  // lanes >= i read past the row's diagonal: masked below
-                z = (int) lane < i ? __builtin_fmaf(-lij, yi, z) : z;
+                z = lanef < (float) i ? __builtin_fmaf(-lij, yi, z) : z;
             }
         }
         z *= rp;
         if ((int) lane < k) a.Y[(size_t) seg * k + lane] = z;
+        // "a is not positive definite" (src/ALS.cpp:12): a pivot <= 0 or NaN makes its rsq inf / NaN, which reaches every
+        // later column and the solution -- one test of the result instead of one compare per pivot; one count per system
+        // (the k > 64 form counts pivots)
+        const bool broken = (int) lane < k && !(__builtin_fabsf(z) <= 3.0e38f);
+        if (__ballot(broken) != 0 && lane == 0) atomicAdd(a.spd_fail, 1u);
         return;
     } else {
         // k > 64: rows do not fit the register file next to the accumulators; row i is a broadcast
