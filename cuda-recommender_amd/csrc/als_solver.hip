@@ -232,7 +232,8 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     __syncthreads();
     if (a.gram_out) {
         for (int e = (int) lane; e < k * k; e += 64) {
-            const int r = e / k, c = e % k;
+            int r = e / k, c = e % k;
+            if (FULL) { r = 16 * (r & 3) + (r >> 2); c = 16 * (c & 3) + (c >> 2); }  // the permuted image of stage_tiles16_perm
             a.gram_out[e] = r >= c ? L[roff(r) + c] : L[roff(c) + r];
         }
         return;
@@ -327,7 +328,8 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
             }
         }
         z *= rp;
-        if ((int) lane < k) a.Y[(size_t) seg * k + lane] = z;
+        // FULL: the system was factored under the column permutation of stage_tiles16_perm (unknown 16 e + c is column 4 c + e)
+        if ((int) lane < k) a.Y[(size_t) seg * k + (FULL ? 4 * (lane & 15) + (lane >> 4) : lane)] = z;
         // "a is not positive definite" (src/ALS.cpp:12): a pivot <= 0 or NaN makes its rsq inf / NaN, which reaches every
         // later column and the solution -- one test of the result instead of one compare per pivot; one count per system
         // (the k > 64 form counts pivots)
@@ -561,6 +563,34 @@ __device__ __forceinline__ void stage_tiles16(f32x4 (&acc)[kTiles16], float (&ba
     }
 }
 
+// k = 64: the same image under the symmetric permutation "column 4 c + e -> 16 e + c", i.e. in the order the MFMA tiles
+// hold it.  Tile (e, f), e <= f, of lane (c, g) holds G'[16 e + 4 g + r][16 f + c], r = 0..3: mirrored, four CONSECUTIVE
+// entries of row 16 f + c of the packed lower triangle -- one ds_write_b128 per tile, ten in all, where the natural order
+// needs forty ds_write_b32 with a row-or-column select each (a Cholesky factorisation is as good under one symmetric
+// permutation as under another; the solution is written back through the inverse permutation).  Diagonal tiles: the
+// lanes whose four entries lie (at least partly) on or below the diagonal of their row write, g <= c >> 2; what reaches
+// past the diagonal lands in the row's alignment padding; the entries of the other lanes are the mirror images of those.
+__device__ __forceinline__ void stage_tiles16_perm(f32x4 (&acc)[kTiles16], float (&bacc)[kSets], float* lds) {
+    const uint32_t lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    float* L = lds;
+    float* bv = lds + roff(64);
+    int ti = 0;
+#pragma unroll
+    for (int e = 0; e < kSets; ++e) {
+#pragma unroll
+        for (int f = e; f < kSets; ++f, ++ti) {
+            float* dst = L + roff(16 * f + (int) c) + 16 * e + 4 * (int) g;
+            if (f > e || g <= (c >> 2)) *reinterpret_cast<f32x4*>(dst) = acc[ti];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < kSets; ++e) {  // rhs: the four row groups hold partial sums of the same column
+        float t = bacc[e] + __shfl_xor(bacc[e], 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (g == 0) bv[16 * e + c] = t;
+    }
+}
+
 // Pipeline state of k_als_gram16: D register sets, used in turn by consecutive 16-row steps (no copies).
 constexpr int kU16 = 4;  // 4-row MFMA groups per step: 16 gathered rows (4 KB) per set
 template <int D>
@@ -704,7 +734,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         return;
     }
     float bacc[kSets] = {r.bacc[0].x, r.bacc[0].y, r.bacc[1].x, r.bacc[1].y};
-    stage_tiles16(r.acc, bacc, lds);
+    if constexpr (FULL) stage_tiles16_perm(r.acc, bacc, lds);
+    else stage_tiles16(r.acc, bacc, lds);
     factor_solve<2, FULL>(lds, a, it.seg);
 }
 
