@@ -244,8 +244,9 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     // Left-looking Cholesky on the lower triangle, row i at a time (the reference's choldc1 loop,
     // src/ALS.cpp:6-23):  sum = A[i][j] - sum_q L[i][q] * L[j][q];  j == i: p = sqrt(sum);  else
     // L[j][i] = sum / p.  The dot product over q runs in four independent partial sums (the
-    // reference's single accumulator would be a 64-deep dependent chain per row); products and sums
-    // stay unfused.  Same arithmetic in both variants below, so they agree bit for bit.
+    // reference's single accumulator would be a 64-deep dependent chain per row).  k <= 64 and the blocked form use
+    // fused multiply-adds and one 1/sqrt(pivot) scale per column; the legacy k > 64 row-by-row form keeps the
+    // unfused arithmetic of round 1.
     if constexpr (NT >= 3 && kBlockedCholesky) {  // (measured at k = 64: 16.9 ms per iteration blocked vs 15.9 in registers)
         bool spd_ok = true;
         chol_blocked<NT>(L, spd_ok);
@@ -258,8 +259,8 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
         // so later rows find it there and the image is complete for the triangular solves.  Against
         // reading both rows from LDS this halves the LDS traffic (which bounded the user half-sweep,
         // 480 k systems) and drops the per-lane address arithmetic.
-        // Register pairs and explicit 2-wide products / sums: v_pk_mul_f32 + v_pk_add_f32 on naturally
-        // aligned pairs (left to itself the SLP vectoriser pairs non-adjacent columns and pays for it in v_mov).
+        // Register pairs and explicit 2-wide fused products: v_pk_fma_f32 on naturally aligned pairs (left to
+        // itself the SLP vectoriser pairs non-adjacent columns and pays for it in v_mov).
         f32x2 r2[KP / 2];
         const int row = (int) lane < KP ? (int) lane : KP - 1;  // KP = 32: the upper half-wave mirrors row 31, never stores
 #pragma unroll
