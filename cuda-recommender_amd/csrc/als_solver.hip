@@ -835,6 +835,9 @@ int launch_half(const AlsArgs& a, uint32_t nitems, uint32_t nreduces, uint64_t n
 
 constexpr uint32_t kAlsChunk = 2048;  // gathered rows per wavefront before a segment is split
 constexpr uint32_t kAlsPad = 128;     // entries behind the index / value arrays (see AlsHalf::build)
+// k_als_gram16 at pipeline depth D loads the indices of step s + D while it works on step s: at most 16 (D + 1) + 15
+// entries past an item's end
+static_assert(kAlsPad >= 16 * ((MFX_G16_DL > MFX_G16_DS ? MFX_G16_DL : MFX_G16_DS) + 2), "index / value padding too short for the pipeline depth");
 
 }  // namespace
 
