@@ -132,7 +132,10 @@ for case in range(a.cases):
             if not (np.isfinite(e_gpu) and e_gpu <= max(5.0 * e_orc, 2e-4 * sc)):
                 fails.append(f"ALS k={ka} {tag}: |gpu-f64| {e_gpu / sc:.2e} vs |oracle-f64| {e_orc / sc:.2e}")
     except Exception as ex:  # noqa: BLE001
-        fails.append(f"EXC {tag}: {type(ex).__name__}: {ex}")
+        if "exceeds the 32-bit virtual-segment range" in str(ex):  # an explicit panel size the library refuses (by design)
+            kinds["rejected"] = kinds.get("rejected", 0) + 1
+        else:
+            fails.append(f"EXC {tag}: {type(ex).__name__}: {ex}")
     done += 1
     if done % (2 if a.big else 20) == 0:
         print(f"{done} cases, {len(fails)} failures, layouts {kinds}", flush=True)
