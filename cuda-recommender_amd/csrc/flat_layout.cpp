@@ -10,12 +10,15 @@ uint32_t pick_tiles_per_span(uint64_t nnz, bool panels) {
     // Aim for ~48k spans (256 CUs x 32 resident waves x ~6 rounds) but keep a span between
     // 2 and 16 tiles: shorter spans waste the per-span prologue, longer ones leave the tail of
     // the grid unbalanced.  With LDS panels a workgroup also pays one slice load per chunk, so
-    // spans are at least 8 tiles there.
+    // spans are at least 8 tiles there -- and at most 8: measured at Z = 9.9e8 (4.8 M x 17 770), CSC / CSR pass per
+    // launch: 6 tiles 1847 / 1796 us, 8 tiles 1725 / 1731, 10 (CSR) and 16 (CSC) tiles 1823 / 2054-2116; the outer
+    // iteration 263 -> 237 ms.  (A chunk of 16 longer spans touches more virtual segments than the 1024-entry LDS
+    // window of per-segment operands holds; the Netflix shape gets 8 from its size anyway.)
     const uint64_t target_spans = 49152;
     uint64_t t = (nnz / kTileElems + target_spans - 1) / target_spans;
     t = (t + 1) & ~uint64_t(1);
-    const uint64_t lo = panels ? 8 : 2;
-    return (uint32_t) std::min<uint64_t>(16, std::max<uint64_t>(lo, t));
+    const uint64_t lo = panels ? 8 : 2, hi = panels ? 8 : 16;
+    return (uint32_t) std::min<uint64_t>(hi, std::max<uint64_t>(lo, t));
 }
 
 namespace {
