@@ -14,11 +14,19 @@ uint32_t pick_tiles_per_span(uint64_t nnz, bool panels) {
     // launch: 6 tiles 1847 / 1796 us, 8 tiles 1725 / 1731, 10 (CSR) and 16 (CSC) tiles 1823 / 2054-2116; the outer
     // iteration 263 -> 237 ms.  (A chunk of 16 longer spans touches more virtual segments than the 1024-entry LDS
     // window of per-segment operands holds; the Netflix shape gets 8 from its size anyway.)
+    if (panels) {
+        // Mid-sized matrices: as few tiles as still put all workgroups (16 spans each) into ONE round of the 512
+        // resident ones -- ML-10M shape (1e7 ratings, k = 64): 8 tiles = 305 workgroups 5.41 ms per outer iteration,
+        // 6 tiles = 407 workgroups 4.38 ms, 4 tiles = 610 workgroups (a second, thin round) 4.68 ms.
+        const uint64_t per_tile_round = 16ull * kTileElems * 512;
+        uint64_t t = (nnz + per_tile_round - 1) / per_tile_round;
+        t = (t + 1) & ~uint64_t(1);
+        return (uint32_t) std::min<uint64_t>(8, std::max<uint64_t>(4, t));
+    }
     const uint64_t target_spans = 49152;
     uint64_t t = (nnz / kTileElems + target_spans - 1) / target_spans;
     t = (t + 1) & ~uint64_t(1);
-    const uint64_t lo = panels ? 8 : 2, hi = panels ? 8 : 16;
-    return (uint32_t) std::min<uint64_t>(hi, std::max<uint64_t>(lo, t));
+    return (uint32_t) std::min<uint64_t>(16, std::max<uint64_t>(2, t));
 }
 
 namespace {
