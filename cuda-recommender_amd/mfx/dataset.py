@@ -198,20 +198,55 @@ def read_dataset_dir(path: str) -> RatingData:
     return d
 
 
+def _read_triplets(pth: str, sep: Optional[str]):
+    """(row, col, rating) columns of a ratings text file.  Formats met in the wild for the datasets the reference's
+    scripts name (scripts/times.sh:15-35): `i j r` (LIBPMF), `user<TAB>item<TAB>rating<TAB>timestamp` (ML-100K u.data),
+    `user::item::rating::timestamp` (ML-1M / ML-10M ratings.dat), `userId,movieId,rating,timestamp` under a header line
+    (ML-20M ratings.csv).  Further columns are ignored; `sep` None = detect."""
+    with open(pth) as f:
+        first = f.readline()
+        tokens = first.replace("::", " ").replace(",", " ").split()
+        header = bool(tokens) and not tokens[0].lstrip("+-").replace(".", "", 1).isdigit()
+        if sep is None:
+            sep = "::" if "::" in first else ("," if "," in first else None)
+        rest = f.read()
+    text = rest if header else first + rest
+    if sep == "::":  # numpy's reader wants a one-character delimiter
+        text, sep = text.replace("::", " "), None
+    import io
+    a = np.loadtxt(io.StringIO(text), delimiter=sep, usecols=(0, 1, 2), dtype=np.float64, ndmin=2)
+    return a[:, 0].astype(np.int64), a[:, 1].astype(np.int64), a[:, 2].astype(np.float32)
+
+
 def convert_text_ratings(train_path: str, out_dir: str, test_path: Optional[str] = None,
-                         one_based: bool = True, sep: Optional[str] = None) -> RatingData:
-    """Converter for "i j r" text files (MovieLens/Netflix style triplets) into the binary
-    directory format -- the tool the reference's authors used but never shipped."""
-    def rd(pth):
-        a = np.loadtxt(pth, delimiter=sep, usecols=(0, 1, 2), dtype=np.float64, ndmin=2)
-        off = 1 if one_based else 0
-        return a[:, 0].astype(np.int64) - off, a[:, 1].astype(np.int64) - off, a[:, 2].astype(np.float32)
-    r, c, v = rd(train_path)
+                         one_based: bool = True, sep: Optional[str] = None, compact_ids: bool = False) -> RatingData:
+    """Converter for ratings text files (see _read_triplets for the formats) into the binary directory format -- the
+    tool the reference's authors used but never shipped.  compact_ids: renumber the row / column ids that
+    occur (train and test together) 0 .. n-1 in ascending order of id -- MovieLens item ids have gaps -- and write the
+    original ids to row_ids.txt / col_ids.txt next to the dataset."""
+    off = 1 if one_based else 0
+    r, c, v = _read_triplets(train_path, sep)
     tr = tc = tv = None
     if test_path:
-        tr, tc, tv = rd(test_path)
-    rows = int(max(r.max(), tr.max() if tr is not None and tr.size else 0)) + 1
-    cols = int(max(c.max(), tc.max() if tc is not None and tc.size else 0)) + 1
+        tr, tc, tv = _read_triplets(test_path, sep)
+    if compact_ids:
+        rid = np.unique(np.concatenate([r, tr]) if tr is not None else r)
+        cid = np.unique(np.concatenate([c, tc]) if tc is not None else c)
+        r, c = np.searchsorted(rid, r), np.searchsorted(cid, c)
+        if tr is not None:
+            tr, tc = np.searchsorted(rid, tr), np.searchsorted(cid, tc)
+        rows, cols = int(rid.size), int(cid.size)
+    else:
+        r, c = r - off, c - off
+        if tr is not None:
+            tr, tc = tr - off, tc - off
+        if r.size and (r.min() < 0 or c.min() < 0):
+            raise ValueError("negative index after the one_based shift: is the file 0-based?")
+        rows = int(max(r.max(initial=-1), tr.max(initial=-1) if tr is not None else -1)) + 1
+        cols = int(max(c.max(initial=-1), tc.max(initial=-1) if tc is not None else -1)) + 1
     d = from_coo(rows, cols, r, c, v, tr, tc, tv)
     write_dataset_dir(out_dir, d)
+    if compact_ids:
+        np.savetxt(os.path.join(out_dir, "row_ids.txt"), rid, fmt="%d")
+        np.savetxt(os.path.join(out_dir, "col_ids.txt"), cid, fmt="%d")
     return d

@@ -102,6 +102,27 @@ def test_text_converter(mfx, tmp_path):
     assert np.array_equal(mfx.dataset.read_dataset_dir(str(tmp_path / "out")).csr_val, d.csr_val)
 
 
+def test_converter_reads_the_movielens_file_formats(mfx, tmp_path):
+    """ML-100K u.data (tabs + timestamp), ML-1M ratings.dat (`::`), ML-20M ratings.csv (header, commas, item ids with
+    gaps -> compact_ids): the same five ratings in every dress give the same matrix."""
+    trip = [(1, 1, 5.0), (1, 3, 3.0), (2, 2, 4.0), (3, 1, 1.0), (3, 3, 2.5)]
+    (tmp_path / "u.data").write_text("".join(f"{i}\t{j}\t{r:g}\t88125{n}\n" for n, (i, j, r) in enumerate(trip)))
+    (tmp_path / "ratings.dat").write_text("".join(f"{i}::{j}::{r:g}::97830{n}\n" for n, (i, j, r) in enumerate(trip)))
+    gap = {1: 10, 2: 200, 3: 3000}  # item ids with gaps
+    (tmp_path / "ratings.csv").write_text("userId,movieId,rating,timestamp\n" +
+                                          "".join(f"{i},{gap[j]},{r:g},11{n}\n" for n, (i, j, r) in enumerate(trip)))
+    ref = mfx.dataset.convert_text_ratings(str(tmp_path / "u.data"), str(tmp_path / "a"))
+    assert (ref.rows, ref.cols, ref.nnz) == (3, 3, 5) and list(ref.csr_val) == [5, 3, 4, 1, 2.5]
+    b = mfx.dataset.convert_text_ratings(str(tmp_path / "ratings.dat"), str(tmp_path / "b"))
+    c = mfx.dataset.convert_text_ratings(str(tmp_path / "ratings.csv"), str(tmp_path / "c"), compact_ids=True)
+    for d in (b, c):
+        assert (d.rows, d.cols, d.nnz) == (3, 3, 5)
+        assert np.array_equal(d.csr_row_ptr, ref.csr_row_ptr) and np.array_equal(d.csr_col_idx, ref.csr_col_idx)
+        assert np.array_equal(d.csc_val, ref.csc_val)
+    assert (tmp_path / "c" / "col_ids.txt").read_text().split() == ["10", "200", "3000"]
+    assert np.array_equal(mfx.dataset.read_dataset_dir(str(tmp_path / "c")).csc_row_idx, ref.csc_row_idx)
+
+
 def test_partition_rows_is_nnz_balanced_and_shards_reassemble(mfx):
     d = mfx.dataset.synth_ratings(997, 211, 30000, seed=5, skew=1.0, test_frac=0.02, empty_row_frac=0.05)
     for g in (1, 2, 3, 8):
