@@ -440,7 +440,13 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     if (pr >= G) pr = G;  // the whole gathered vector fits: one panel
     const uint64_t npanels = (G + pr - 1) / pr;
     const double mean_vseg = (double) nnz / ((double) npanels * (double) (nseg ? nseg : 1));
-    if (p.panel_rows == 0 && npanels > 1 && mean_vseg < 8.0) {
+    // ... unless the matrix is small enough that the per-(panel, segment) bookkeeping stays cheap: up to 8 M virtual
+    // segments the LDS panels still win (700 000 x 40 000 with 3e7 / 1.5e7 / 8e6 ratings, 7.1 / 3.6 / 1.9 entries per
+    // pair: 7.7 / 5.4 / 3.9 ms per outer iteration at k = 32 against 10.1 / 7.3 / 5.1 ms in the scatter layout; at 2.8e7
+    // virtual segments -- 2 M x 100 k, 1 M x 200 k -- the scatter layout wins by 1.4x, at 1.75e8 -- config 5's shard --
+    // by 2.4x: k_finalize's cost grows with the virtual segments, the scatter pass's with the panels).
+    const bool small_dims = npanels * (uint64_t) (nseg ? nseg : 1) <= 8000000ull && mean_vseg >= 1.5;
+    if (p.panel_rows == 0 && npanels > 1 && mean_vseg < 8.0 && !small_dims) {
         // LDS-sized panels would shred the segments (hyper-sparse shard: < 8 entries per (panel, segment)
         // pair).  Cut at L2 granularity instead: 2 MB slices keep every gather an L2 hit (measured,
         // tools/ubench_gather.hip sweep: 100 M 8-byte gathers take 0.60 ms against a 2 MB table, 1.01 ms
