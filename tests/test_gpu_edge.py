@@ -134,6 +134,16 @@ def test_hyper_sparse_shard_layouts(mfx, orc):
     _check(mfx, orc, d, 2, t=2, panel_rows=-262144)   # cache panels forced, device-built
 
 
+def test_small_hyper_sparse_matrices_stay_on_lds_panels(mfx, orc):
+    """300 k x 20 k with 5 M ratings: 3.3 / 6 entries per (panel, segment) pair -- below the 8 at which big matrices
+    switch to the scatter layout -- but only 1.5 M / 0.84 M pairs: k_finalize stays cheap and the LDS panels are the
+    faster layout (choose_layout, ccd_solver.hip).  Oracle results either way."""
+    d = mfx.dataset.synth_ratings(300000, 20000, 5000000, seed=33, skew=0.5, test_frac=0.002)
+    assert _kinds(mfx, d) == ("lds", "lds")
+    _check(mfx, orc, d, 2, t=2)
+    _check(mfx, orc, d, 2, t=2, kernel_variant=2)  # the scatter layout, forced, on the same data
+
+
 def _kinds(mfx, d, **kw):
     s = mfx.CcdSolver(d, None, _p(mfx, 2, **kw))
     info = s.layout_info()
