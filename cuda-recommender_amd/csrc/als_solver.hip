@@ -46,13 +46,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }  // v_pk_fma_f32
 
-// 1 / sqrt(x) for a pivot (normal range, > 0): v_rsq_f32 (1 ulp) + one Newton step.  A non-positive or NaN pivot
-// gives NaN / inf, which the caller has already flagged as an SPD failure.
-__device__ __forceinline__ float rsqrt_nr(float x) {
-    const float y = __builtin_amdgcn_rsqf(x);
-    const float e = __builtin_fmaf(-x * y, y, 1.0f);
-    return __builtin_fmaf(0.5f * y, e, y);
-}
 // 1 / x: v_rcp_f32 (1 ulp) + one Newton step
 __device__ __forceinline__ float rcp_nr(float x) {
     const float r = __builtin_amdgcn_rcpf(x);
@@ -170,10 +163,10 @@ __device__ __forceinline__ void chol_panel_pass(float* __restrict__ L, int J, in
         if constexpr (DIAG) {
             const float piv = rl(sum, i);  // lane i < 32 owns the diagonal entry
             spd_ok = spd_ok && piv > 0.f;
-            lji = sum * rsqrt_nr(piv);     // lane i: pivot / sqrt(pivot) = the diagonal entry (see factor_solve, k <= 64)
+            lji = sum * __builtin_amdgcn_rsqf(piv);  // lane i: pivot / sqrt(pivot) = the diagonal entry (see factor_solve, k <= 64)
             if (stores && (h || lane >= i)) blk[i] = lji;
         } else {
-            lji = sum * rcp_nr(pivrow[i]);
+            lji = sum * __builtin_amdgcn_rcpf(pivrow[i]);  // (1 ulp, like the rsq of the diagonal pass)
             if (stores) blk[i] = lji;
         }
         r2[i / 2][i & 1] = lji;  // (diagonal block, lanes above the pivot: a slot they never read)
