@@ -219,16 +219,22 @@ def _read_triplets(pth: str, sep: Optional[str]):
 
 
 def convert_text_ratings(train_path: str, out_dir: str, test_path: Optional[str] = None,
-                         one_based: bool = True, sep: Optional[str] = None, compact_ids: bool = False) -> RatingData:
+                         one_based: bool = True, sep: Optional[str] = None, compact_ids: bool = False,
+                         test_frac: float = 0.0, seed: int = 0) -> RatingData:
     """Converter for ratings text files (see _read_triplets for the formats) into the binary directory format -- the
     tool the reference's authors used but never shipped.  compact_ids: renumber the row / column ids that
     occur (train and test together) 0 .. n-1 in ascending order of id -- MovieLens item ids have gaps -- and write the
-    original ids to row_ids.txt / col_ids.txt next to the dataset."""
+    original ids to row_ids.txt / col_ids.txt next to the dataset.  test_frac > 0 (and no test file): that fraction of
+    the ratings, drawn with `seed`, becomes the test set -- the distributed files are not split."""
     off = 1 if one_based else 0
     r, c, v = _read_triplets(train_path, sep)
     tr = tc = tv = None
     if test_path:
         tr, tc, tv = _read_triplets(test_path, sep)
+    elif test_frac > 0.0:
+        held = np.random.default_rng(seed).random(r.size) < test_frac
+        tr, tc, tv = r[held], c[held], v[held]
+        r, c, v = r[~held], c[~held], v[~held]
     if compact_ids:
         rid = np.unique(np.concatenate([r, tr]) if tr is not None else r)
         cid = np.unique(np.concatenate([c, tc]) if tc is not None else c)

@@ -120,6 +120,8 @@ def test_converter_reads_the_movielens_file_formats(mfx, tmp_path):
         assert np.array_equal(d.csr_row_ptr, ref.csr_row_ptr) and np.array_equal(d.csr_col_idx, ref.csr_col_idx)
         assert np.array_equal(d.csc_val, ref.csc_val)
     assert (tmp_path / "c" / "col_ids.txt").read_text().split() == ["10", "200", "3000"]
+    h = mfx.dataset.convert_text_ratings(str(tmp_path / "ratings.dat"), str(tmp_path / "h"), test_frac=0.5, seed=1)
+    assert h.nnz + h.nnz_test == 5 and 0 < h.nnz_test < 5 and (h.rows, h.cols) == (3, 3)
     assert np.array_equal(mfx.dataset.read_dataset_dir(str(tmp_path / "c")).csc_row_idx, ref.csc_row_idx)
 
 
