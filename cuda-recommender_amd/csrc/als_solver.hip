@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <type_traits>
 
 #include "ccd_kernels.hpp"
 
@@ -420,62 +421,137 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(als_waves(NT
 #pragma unroll
     for (int I = 0; I < NT; ++I) bacc[I] = 0.f;
 
-    constexpr int U = NT >= 3 ? 4 : 8;  // gathered row pairs per batch (two batches in flight)
-    // Same pipeline as k_als_gram16: indices / ratings two batches ahead, factor rows one batch ahead,
-    // every load unconditional -- positions past the segment's end and columns past k gather from the
-    // all-zero row X[x_rows].
-    // A position past the segment's end loads the SENTINEL entry of the index / value arrays (the zero row, rating 0):
-    // a select between two positions of one array.  Written as `q < hi ? idx[q] : x_rows` the conditional is folded
-    // into a select between two ADDRESSES (the index array, the slot holding x_rows) feeding one flat_load -- which
-    // counts on lgkmcnt as well as vmcnt, so every batch began with `s_waitcnt vmcnt(0) lgkmcnt(0)`: all loads in
-    // flight drained, the one issued two instructions earlier included (58 % of the MFMA rate).
-    const uint32_t zrow = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.x_rows);
-    uint32_t row_n[U];
-    float rv_n[U], rv_c[U];
-    float av_n[U][NT];
-    auto load_idx = [&](uint32_t q0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t q = q0 + 2 * u + h;
-            const uint32_t qe = q < it.hi ? q : a.sentinel;
-            row_n[u] = a.idx[qe];
-            rv_n[u] = a.val[qe];
-        }
-    };
-    auto load_rows = [&]() {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int I = 0; I < NT; ++I) {
-                const uint32_t col = I * 32 + c31;
-                const bool in = col < k;
-                av_n[u][I] = a.X[(size_t) (in ? row_n[u] : zrow) * k + (in ? col : 0u)];
+    constexpr int U = NT >= 3 ? 4 : 8;  // gathered row pairs per step
+    if constexpr (NT >= 3) {
+        // The pipeline of k_als_gram16 in its generic form (64-bit addressing: this kernel also takes the gather tables
+        // that one cannot): two register sets used alternately by consecutive steps of 2 U entries, no copies -- MFMAs of
+        // step s on one set while the factor rows (and ratings) of step s + 1 load into the other and the indices of step
+        // s + 2 load behind them.  Positions past the segment's end load the SENTINEL entry of the index / value arrays
+        // (zero row, rating 0); columns past k gather the zero row.  (As a compiler-scheduled loop with "next" and
+        // "current" arrays the copies between the two forced `s_waitcnt vmcnt(0)` on the loads just issued in front of
+        // every MFMA block: at one wave per SIMD, k = 128, the whole gather latency of every step lay open.)
+        const uint32_t zrow = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.x_rows);
+        uint32_t ix[2][U];
+        float rv[2][U];
+        float av[2][U][NT];
+        auto load_idx = [&](auto S, uint32_t q0) {
+            constexpr int s = decltype(S)::value;
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t q = q0 + 2 * u + h;
+                ix[s][u] = a.idx[q < it.hi ? q : a.sentinel];
             }
-            rv_c[u] = rv_n[u];
+        };
+        auto load_rows = [&](auto S, uint32_t q0) {
+            constexpr int s = decltype(S)::value;
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t row = ix[s][u];
+                asm volatile("" : "+v"(row));  // opaque use: keeps the index load where it was issued (see g16_load_rows)
+                const uint32_t q = q0 + 2 * u + h;
+                rv[s][u] = a.val[q < it.hi ? q : a.sentinel];
+    #pragma unroll
+                for (int I = 0; I < NT; ++I) {
+                    const uint32_t col = I * 32 + c31;
+                    const bool in = col < k;
+                    av[s][u][I] = a.X[(size_t) (in ? row : zrow) * k + (in ? col : 0u)];
+                }
+            }
+        };
+        auto mfmas = [&](auto S) {
+            constexpr int s = decltype(S)::value;
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int ti = 0;
+    #pragma unroll
+                for (int I = 0; I < NT; ++I) {
+                    bacc[I] += rv[s][u] * av[s][u][I];
+    #pragma unroll
+                    for (int J = I; J < NT; ++J, ++ti)
+                        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][u][I], av[s][u][J], acc[ti], 0, 0, 0);
+                }
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        load_idx(S0{}, it.lo);
+        load_idx(S1{}, it.lo + 2 * U);
+        load_rows(S0{}, it.lo);
+        for (uint32_t q0 = it.lo;;) {
+            load_rows(S1{}, q0 + 2 * U);
+            load_idx(S0{}, q0 + 4 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(S0{});
+            __builtin_amdgcn_sched_barrier(0);
+            q0 += 2 * U;
+            if (q0 >= it.hi) break;
+            load_rows(S0{}, q0 + 2 * U);
+            load_idx(S1{}, q0 + 4 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(S1{});
+            __builtin_amdgcn_sched_barrier(0);
+            q0 += 2 * U;
+            if (q0 >= it.hi) break;
         }
-    };
-    load_idx(it.lo);
-    load_rows();
-    load_idx(it.lo + 2 * U);
-    for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 2 * U) {
-        float av[U][NT], rv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            rv[u] = rv_c[u];
-#pragma unroll
-            for (int I = 0; I < NT; ++I) av[u][I] = av_n[u][I];
-        }
+    } else {
+        // k <= 64 (3 to 6 waves per SIMD): the compiler-scheduled form of the same pipeline, which is the faster
+        // one there (k = 32: 7.9 ms per iteration against 9.0 ms for the explicit two-set form)
+        // Same pipeline as k_als_gram16: indices / ratings two batches ahead, factor rows one batch ahead,
+        // every load unconditional -- positions past the segment's end and columns past k gather from the
+        // all-zero row X[x_rows].
+        // A position past the segment's end loads the SENTINEL entry of the index / value arrays (the zero row, rating 0):
+        // a select between two positions of one array.  Written as `q < hi ? idx[q] : x_rows` the conditional is folded
+        // into a select between two ADDRESSES (the index array, the slot holding x_rows) feeding one flat_load -- which
+        // counts on lgkmcnt as well as vmcnt, so every batch began with `s_waitcnt vmcnt(0) lgkmcnt(0)`: all loads in
+        // flight drained, the one issued two instructions earlier included (58 % of the MFMA rate).
+        const uint32_t zrow = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.x_rows);
+        uint32_t row_n[U];
+        float rv_n[U], rv_c[U];
+        float av_n[U][NT];
+        auto load_idx = [&](uint32_t q0) {
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t q = q0 + 2 * u + h;
+                const uint32_t qe = q < it.hi ? q : a.sentinel;
+                row_n[u] = a.idx[qe];
+                rv_n[u] = a.val[qe];
+            }
+        };
+        auto load_rows = [&]() {
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+    #pragma unroll
+                for (int I = 0; I < NT; ++I) {
+                    const uint32_t col = I * 32 + c31;
+                    const bool in = col < k;
+                    av_n[u][I] = a.X[(size_t) (in ? row_n[u] : zrow) * k + (in ? col : 0u)];
+                }
+                rv_c[u] = rv_n[u];
+            }
+        };
+        load_idx(it.lo);
         load_rows();
-        load_idx(q0 + 4 * U);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int ti = 0;
-#pragma unroll
-            for (int I = 0; I < NT; ++I) {
-                bacc[I] += rv[u] * av[u][I];
-#pragma unroll
-                for (int J = I; J < NT; ++J, ++ti)
-                    acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][I], av[u][J], acc[ti], 0, 0, 0);
+        load_idx(it.lo + 2 * U);
+        for (uint32_t q0 = it.lo; q0 < it.hi; q0 += 2 * U) {
+            float av[U][NT], rv[U];
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rv[u] = rv_c[u];
+    #pragma unroll
+                for (int I = 0; I < NT; ++I) av[u][I] = av_n[u][I];
+            }
+            load_rows();
+            load_idx(q0 + 4 * U);
+    #pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int ti = 0;
+    #pragma unroll
+                for (int I = 0; I < NT; ++I) {
+                    bacc[I] += rv[u] * av[u][I];
+    #pragma unroll
+                    for (int J = I; J < NT; ++J, ++ti)
+                        acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][I], av[u][J], acc[ti], 0, 0, 0);
+                }
             }
         }
     }
