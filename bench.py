@@ -85,6 +85,16 @@ def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
     s.close()
 
 
+def kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) over the CCD++ kernel sources: what ties a PMC record in profiles/traffic.json
+    to the kernels it was measured on (tools/collect_profiles.py writes the same value)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("ccd_kernels.hip", "ccd_scatter.hip", "flat_layout.hpp"):
+        h.update(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def free_port() -> int:
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
@@ -95,27 +105,46 @@ def free_port() -> int:
 def launch_workers(n: int, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh worker processes of this script (one
     per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), relay rank 0's
-    stdout (the single JSON line), exit with the workers' status.  Runs before anything touches the GPU."""
+    stdout (the single JSON line), exit with the workers' status.  Runs before anything touches the GPU.
+    ALL children are supervised: the first one that exits non-zero (an out-of-memory kill while the matrix is
+    generated, a failed setup) ends the run -- the others, which would otherwise sit in a collective waiting
+    for it until the driver's timeout, are terminated (the exact children started here, nothing else), and
+    that status is returned with a one-line diagnosis on stderr."""
     import subprocess
+    import tempfile
     env0 = dict(os.environ)
     env0.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
                  "LOCAL_WORLD_SIZE": str(n)})
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out0 = tempfile.TemporaryFile()
     procs = []
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc, live = 0, set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code
+                print(f"[bench launcher] rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                break
+        else:
+            time.sleep(0.2)
+    for r in sorted(live):  # only after a failure: the survivors are waiting for a rank that is gone
+        procs[r].terminate()
+    for r in sorted(live):
         try:
-            p.wait(timeout=120 if rc == 0 else 5)
+            procs[r].wait(timeout=10)
         except subprocess.TimeoutExpired:
-            p.kill()  # the exact children started above, nothing else
-            p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out0.decode(errors="replace"))
+            procs[r].kill()
+            procs[r].wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode(errors="replace"))
     sys.stdout.flush()
     return rc
 
@@ -128,6 +157,8 @@ def dry_run(a) -> None:
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.dry_run_fail_rank == rank:  # (test hook) this rank dies before it joins the collective
+        raise SystemExit(3)
     t = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.init_process_group("gloo")
@@ -169,22 +200,27 @@ def main() -> None:
     ap.add_argument("--no-rank-one", action="store_true",
                     help="skip the standalone rank-one sweep measurement (one extra outer iteration at T = 2, N = 1 only)")
     ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
-    ap.add_argument("--workload", choices=["netflix", "config5"], default="netflix",
+    ap.add_argument("--workload", choices=["netflix", "config5", "nnz1e9"], default="netflix",
                     help="netflix: BASELINE configs[2], one 480189-row block per GPU (weak scaling, the metric's "
                          "config); config5: BASELINE configs[4], one global 10M x 1M x 1e9 matrix at k = 128 "
-                         "row-sharded over the ranks (strong scaling)")
+                         "row-sharded over the ranks (strong scaling); nnz1e9: the north star's target point "
+                         "'k = 64, nnz = 1e9' on one GPU -- ten Netflix-sized user blocks, 4801890 x 17770, 990721120 ratings")
     ap.add_argument("--dry-run", action="store_true", help="launch plumbing only (gloo, no GPU)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="(with --dry-run) this rank exits with status 3 before the collective")
     a = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:  # bare `python bench.py --gpus N`: be the launcher
         raise SystemExit(launch_workers(a.gpus, sys.argv[1:]))
     if a.dry_run:
         return dry_run(a)
+    given = {x.split("=")[0] for x in sys.argv[1:] if x.startswith("--")}
     if a.workload == "config5":  # shape defaults of configs[4] unless given explicitly
-        given = {x.split("=")[0] for x in sys.argv[1:] if x.startswith("--")}
         if "--rows" not in given: a.rows = 10_000_000
         if "--cols" not in given: a.cols = 1_000_000
         if "--nnz" not in given: a.nnz = 1_000_000_000
         if "--k" not in given: a.k = 128
+    if a.workload == "nnz1e9":
+        if "--rows" not in given: a.rows = 4_801_890
+        if "--nnz" not in given: a.nnz = 990_721_120
 
     import numpy as np
     import torch
@@ -208,6 +244,8 @@ def main() -> None:
     # ---------------- synthetic input, generated in HBM ----------------
     t0 = time.time()
     strong = a.workload == "config5"
+    d_sigma = ((0.5 if a.sigma_rows is None else a.sigma_rows, 1.0 if a.sigma_cols is None else a.sigma_cols) if strong else
+               (1.2 if a.sigma_rows is None else a.sigma_rows, 1.8 if a.sigma_cols is None else a.sigma_cols))
     if strong:
         # every rank draws the SAME global matrix and keeps its nnz-balanced block of user rows;
         # uniform user activity / mild item skew: config 5 is "synthetic 10M x 1M", not a Netflix-shaped one
@@ -321,19 +359,28 @@ def main() -> None:
             secs, launches = cand[dom]
             avg = secs / max(1, launches)
             achieved = alg[dom] / avg / 1e9
-            traffic = None
+            # HBM bytes per launch from the PMC counters: NOT measured in this run (counters need their own rocprofv3
+            # passes) but read from the committed profiles/traffic.json -- and only when that file was collected for
+            # this kernel at this size from these kernel sources; `traffic_source` says which it was
+            traffic, traffic_source = None, "none: no PMC record for this kernel and size in profiles/traffic.json"
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    ent = tj.get(dom)
-                    if ent and int(ent.get("nnz", -1)) == Z:
-                        traffic = ent.get("hbm_bytes_per_launch")
+                    ent = tj.get(f"{dom}@{Z}") or tj.get(dom)
+                    if ent and int(ent.get("nnz", -1)) == Z and int(ent.get("rows", m)) == m and int(ent.get("cols", n)) == n:
+                        if ent.get("kernel_src_sha16") == kernel_source_hash():
+                            traffic = ent.get("hbm_bytes_per_launch")
+                            traffic_source = (f"profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                              f"{ent.get('collected', '?')}, kernel sources {ent.get('kernel_src_sha16')}")
+                        else:
+                            traffic_source = ("stale: the kernel sources changed since profiles/traffic.json was collected "
+                                              f"({ent.get('kernel_src_sha16')} -> {kernel_source_hash()}); rerun tools/prof_r03_final.sh")
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
+                        "traffic_source": traffic_source, "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
                         "algorithmic_bytes_per_launch": int(alg[dom]),
                         "streamed_bytes_per_launch": int(phys[dom]) if (dom in phys and (
                             "scatter" in dom or layout["csr" if "csr" in dom else "csc"]["kind"] == "lds")) else int(alg[dom]),
@@ -375,29 +422,45 @@ def main() -> None:
     cpu_baseline = None
     if world == 1 and not a.no_cpu_baseline:
         from oracle import oracle as orc
-        host = synth_torch.to_rating_data(d)
+        # bounded sample: at most ~1.3e8 ratings -- beyond that the leading nnz-balanced block of user rows (the CPU
+        # cost per rating does not depend on how many blocks follow), SURVEY 8d "for Z = 1e9 run the CPU on a 1/8 shard"
+        cap = 130_000_000
+        blocks = max(1, -(-Z // cap))
+        dc = d if blocks == 1 else synth_torch.leading_row_block(d, blocks)
+        host = synth_torch.to_rating_data(dc)
+        del dc
         threads = orc.max_threads()  # min(OpenMP max, cgroup/affinity share of this box, 32)
         ks = max(1, min(a.cpu_ranks, a.k))
-        Wc = np.ascontiguousarray(W0[:ks])
+        Wc = np.ascontiguousarray(W0[:ks, :host.rows])
         _, _, _, times, _, _ = orc.ccdr1(host, Wc, ks, a.lam, 2, a.inner, threads)
         t_steady = float(times[1].sum())  # outer iteration 2: includes the add-back (src/CCD.cpp:100)
         t_outer_k = t_steady * (a.k / ks)
         cpu_baseline = {"value": round(host.nnz / t_outer_k, 1), "unit": "nnz/s", "cores": threads, "kind": "port",
-                        "sample": f"{ks} of {a.k} ranks, outer iterations 1-2 on the full matrix; steady-state "
-                                  f"iteration 2 ({t_steady:.2f} s) scaled by {a.k}/{ks}"}
+                        "sample": f"{ks} of {a.k} ranks, outer iterations 1-2 on " +
+                                  ("the full matrix" if blocks == 1 else f"the leading 1/{blocks} nnz-balanced block of user rows "
+                                   f"({host.rows} rows, {host.nnz} ratings)") +
+                                  f"; steady-state iteration 2 ({t_steady:.2f} s) scaled by {a.k}/{ks}"}
     solver.close()  # (idempotent)
 
     if rank == 0:
+        if strong:
+            label = (f"synthetic (BASELINE configs[4]): ONE global {a.rows}x{a.cols}, nnz={nnz_global}, "
+                     f"k={a.k}, T={a.inner}, lambda={a.lam}, nnz-balanced user-row blocks over {world} GPU(s)")
+        elif (a.rows, a.cols, a.nnz) == (480189, 17770, 99072112):
+            label = ("Netflix-shaped synthetic (BASELINE configs[2]): per-GPU "
+                     f"{a.rows}x{a.cols}, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam}")
+        elif a.workload == "nnz1e9":
+            label = (f"synthetic, north star's 'k = 64, nnz = 1e9' point (ten Netflix-sized user blocks): per-GPU "
+                     f"{a.rows}x{a.cols}, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam}")
+        else:
+            label = (f"synthetic {a.rows}x{a.cols} per GPU, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam} "
+                     f"(user / item log-normal sigma {d_sigma[0]} / {d_sigma[1]})")
         out = {
-            "metric": "rating-nnz/sec per CCD++ outer iter at k=64", "value": round(value, 1), "unit": "nnz/s",
+            "metric": "rating-nnz/sec per CCD++ outer iter at k=%d" % a.k, "value": round(value, 1), "unit": "nnz/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 6),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"synthetic (BASELINE configs[4]): ONE global {a.rows}x{a.cols}, nnz={nnz_global}, "
-                                    f"k={a.k}, T={a.inner}, lambda={a.lam}, nnz-balanced user-row blocks over {world} GPU(s)")
-                                   if strong else
-                                   ("Netflix-shaped synthetic (BASELINE configs[2]): per-GPU "
-                                    f"{a.rows}x{a.cols}, nnz={nnz_local}, k={a.k}, T={a.inner}, lambda={a.lam}"),
+            "config": {"workload": label,
                        "rows_per_gpu": int(d["rows"]), "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
                        "inner_iters": a.inner, "schedule": "fused" if a.schedule == 1 else "as-written",
                        "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},

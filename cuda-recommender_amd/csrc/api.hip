@@ -272,7 +272,7 @@ static FlatLayoutOptions op_layout(int variant, int64_t nseg, int64_t nnz, int64
     mfx_params p;
     mfx_params_default(&p);
     p.panel_rows = (variant >= 16 || variant <= -16) ? variant : variant == 2 ? 0 : -1;
-    return choose_layout(p, (uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, sizeof(float), variant == 0);
+    return choose_layout(p, (uint32_t) nseg, (uint64_t) nnz, (uint32_t) vec_len, sizeof(float), variant == 0 || variant == -1);
 }
 
 int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint32_t* idx, const float* val,
@@ -291,6 +291,16 @@ int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uin
         MFX_TRY(dvec.alloc(vec_len)); MFX_TRY(dvec.upload(vec, vec_len, MFX_HOST, cx.st));
         MFX_TRY(dout.alloc(nseg));
         FinalizeArgs f; f.lambda = lambda; f.out_vec = dout.get();
+        if (variant == -1) {  // the reference's summation order: sums and division in one kernel (ccd_reforder.hip)
+            std::vector<uint32_t> order;
+            ref_sweep_order(ptr, (uint32_t) nseg, &order);
+            DevBuf<uint32_t> dorder;
+            MFX_TRY(dorder.alloc(order.size())); MFX_TRY(dorder.upload(order.data(), order.size(), MFX_HOST, cx.st));
+            MFX_TRY(launch_sweep_ref(s.view, dorder.get(), dvec.get(), lambda, dout.get(), cx.st));
+            MFX_HIP(hipMemcpyAsync(out, dout.get(), sizeof(float) * nseg, hipMemcpyDeviceToHost, cx.st));
+            MFX_HIP(hipStreamSynchronize(cx.st));
+            return MFX_OK;
+        }
         if (variant == 0) {
             MFX_TRY(gh.alloc_zero((size_t) 2 * nseg, cx.st));
             MFX_TRY(launch_sweep_wave(s.view, dvec.get(), gh.get(), gh.get() + nseg, cx.st));
@@ -321,7 +331,7 @@ int mfx_update_rating(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint
         DevBuf<float> dg, dp;
         MFX_TRY(dg.alloc(vec_len)); MFX_TRY(dg.upload(gathered, vec_len, MFX_HOST, cx.st));
         MFX_TRY(dp.alloc(nseg)); MFX_TRY(dp.upload(per_seg, nseg, MFX_HOST, cx.st));
-        if (variant == 0) MFX_TRY(launch_resid_wave(s.view, dg.get(), dp.get(), add, cx.st));
+        if (variant <= 0 && variant > -16) MFX_TRY(launch_resid_wave(s.view, dg.get(), dp.get(), add, cx.st));
         else MFX_TRY(launch_flat(FM_RESID, s.view, dg.get(), dp.get(), add, cx.st));
         if (nnz) {
             DevBuf<float> tmp;

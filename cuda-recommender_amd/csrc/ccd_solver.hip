@@ -479,7 +479,8 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
 static const char* kKernelNames[KernelProfiler::K_COUNT] = {
     "ccd_fused_csc_pass", "ccd_fused_csr_pass", "ccd_flat_sweep", "ccd_flat_resid", "ccd_finalize",
     "ccd_combine_dense", "ccd_pack", "test_rmse", "rccl_allreduce", "ccd_wave_sweep", "ccd_wave_resid",
-    "ccd_scatter_v_pass", "ccd_scatter_u_pass", "ccd_scatter_sweep", "ccd_scatter_resid", "ccd_scatter_combine"};
+    "ccd_scatter_v_pass", "ccd_scatter_u_pass", "ccd_scatter_sweep", "ccd_scatter_resid", "ccd_scatter_combine",
+    "ccd_ref_order_sweep"};
 
 const char* KernelProfiler::name(int id) { return id >= 0 && id < K_COUNT ? kKernelNames[id] : "?"; }
 
@@ -584,7 +585,11 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // Layouts.  Hyper-sparse shapes (LDS-sized panels would leave < 8 entries per (panel, segment) pair on
     // either side, so that side would fall back to L2 "cache panels") take the scatter layout on BOTH sides
     // (ccd_scatter.hip); kernel_variant = 2 forces it, panel_rows != 0 or kernel_variant = 0 rule it out.
-    const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
+    MFX_REQUIRE(p->kernel_variant >= -1 && p->kernel_variant <= 3, "kernel_variant must be -1 ... 3");
+    MFX_REQUIRE(p->kernel_variant != -1 || p->schedule == 0, "kernel_variant = -1 (reference-order sweeps) goes with schedule = 0");
+    MFX_REQUIRE(p->kernel_variant != -1 || !(shard && shard->comm), "kernel_variant = -1 is a single-GPU parity mode (a sharded sum has no reference order)");
+    ref_order_ = p->kernel_variant == -1;
+    const bool need_plain = p->schedule == 0 && p->kernel_variant <= 0;
     bool want_scatter = p->kernel_variant == 2 || p->kernel_variant == 3;  // 3: scatter with explicit 32-bit ids
     if (!want_scatter && !need_plain && p->panel_rows == 0 && p->layout_build != 1) {
         const FlatLayoutOptions a = choose_layout(*p, m_, nnz_, n_, kCsrSliceBytes, false), b = choose_layout(*p, n_, nnz_, m_, sizeof(float2), false);
@@ -596,6 +601,19 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         rc = build_stores(R, p, space, false);
     }
     MFX_TRY(rc);
+    if (ref_order_) {  // dispatch order of the reference-order sweeps: longest segment first (ccd_reforder.hip)
+        for (int side = 0; side < 2; ++side) {
+            const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
+            std::vector<uint32_t> ptr_h((size_t) v.nseg + 1), order;
+            MFX_HIP(hipMemcpyAsync(ptr_h.data(), v.ptr, sizeof(uint32_t) * ptr_h.size(), hipMemcpyDeviceToHost, st_));
+            MFX_HIP(hipStreamSynchronize(st_));
+            ref_sweep_order(ptr_h.data(), v.nseg, &order);
+            DevBuf<uint32_t>& dst = side == 0 ? ref_order_csc_ : ref_order_csr_;
+            MFX_TRY(dst.alloc(order.size()));
+            MFX_TRY(dst.upload(order.data(), order.size(), MFX_HOST, st_));
+            MFX_HIP(hipStreamSynchronize(st_));
+        }
+    }
 
     MFX_TRY(W_.alloc_zero((size_t) k_ * m_, st_));
     MFX_TRY(H_.alloc_zero((size_t) k_ * n_, st_));
@@ -630,6 +648,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     MFX_REQUIRE(p->eps >= 0.f && p->eps < 1.f, "eps must be in [0, 1)");
     ext_on_ = p->do_nmf != 0 || p->eps > 0.f || p->rank_trace != 0;
     if (p->eps > 0.f || p->rank_trace) MFX_REQUIRE(!comm_, "eps / rank_trace are not available in a sharded solve");
+    MFX_REQUIRE(!ref_order_ || !(p->do_nmf || p->eps > 0.f), "do_nmf / eps are not available with kernel_variant = -1");
     if (p->eps > 0.f) {
         MFX_TRY(fundec_seg_.alloc_zero(std::max(m_, n_), st_));
         MFX_TRY(fundec_sum_.alloc_zero(1, st_));
@@ -649,7 +668,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
 // Both orientations, side by side (the serial stretches of one overlap the parallel passes / transfers of
 // the other).  Error text is thread-local, so it is carried across.
 int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace space, bool scatter) {
-    const bool need_plain = p->schedule == 0 && p->kernel_variant == 0;
+    const bool need_plain = p->schedule == 0 && p->kernel_variant <= 0;
     auto options = [&](uint32_t nseg, uint32_t G, uint32_t elem_bytes) {
         if (!scatter) return choose_layout(*p, nseg, nnz_, G, elem_bytes, need_plain);
         // scatter: 24 B of LDS per local index (operand pair + two 64-bit accumulators) and the whole 160 KB of a CU
@@ -918,6 +937,10 @@ int CcdSolver::sweep(SegStreamStore& s, const float* vec, float* out, bool is_co
         PROF(KernelProfiler::K_SCAT_SWEEP, launch_scatter(SM_SWEEP, src.view, nullptr, vec, 0, st_));
         return scatter_finalize(is_col_side, f);
     }
+    if (ref_order_) {  // g, h and the division in one kernel, in the reference's order; no separate finalize
+        PROF(KernelProfiler::K_SWEEP_REF, launch_sweep_ref(s.view, (is_col_side ? ref_order_csc_ : ref_order_csr_).get(), vec, p_.lambda, out, st_));
+        return MFX_OK;
+    }
     if (p_.kernel_variant == 0) {
         float* gh = is_col_side ? gh_cols_.get() : gh_rows_.get();
         PROF(KernelProfiler::K_SWEEP_WAVE, launch_sweep_wave(s.view, vec, gh, gh + s.view.nseg, st_));
@@ -940,7 +963,7 @@ int CcdSolver::resid(SegStreamStore& s, const float* gathered, const float* per_
         PROF(KernelProfiler::K_SCAT_RESID, launch_scatter(SM_RESID, s.view, gathered, per_seg, add, st_));
         return MFX_OK;
     }
-    if (p_.kernel_variant == 0)
+    if (p_.kernel_variant <= 0)
         PROF(KernelProfiler::K_RESID_WAVE, launch_resid_wave(s.view, gathered, per_seg, add, st_));
     else
         PROF(KernelProfiler::K_RESID, launch_flat(FM_RESID, s.view, gathered, per_seg, add, st_));

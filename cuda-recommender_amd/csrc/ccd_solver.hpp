@@ -71,7 +71,7 @@ public:
     void reset_totals();
     static const char* name(int id);
     enum { K_FCSC = 0, K_FCSR, K_SWEEP, K_RESID, K_FINALIZE, K_COMBINE, K_PACK, K_RMSE, K_ALLREDUCE,
-           K_SWEEP_WAVE, K_RESID_WAVE, K_SCAT_V, K_SCAT_U, K_SCAT_SWEEP, K_SCAT_RESID, K_SCAT_COMBINE, K_COUNT };
+           K_SWEEP_WAVE, K_RESID_WAVE, K_SCAT_V, K_SCAT_U, K_SCAT_SWEEP, K_SCAT_RESID, K_SCAT_COMBINE, K_SWEEP_REF, K_COUNT };
     double seconds[K_COUNT] = {};
     int64_t launches[K_COUNT] = {};
 
@@ -131,6 +131,9 @@ private:
     // scatter mode (hyper-sparse: both stores in the scatter layout, roles swapped -- see ccd_scatter.hip):
     // sums over COLUMNS come from the row-major store csr_, sums over ROWS from csc_
     bool scatter_ = false;
+    // kernel_variant = -1: sweeps in the reference's summation order (ccd_reforder.hip), bit-identical to src/CCD.cpp
+    bool ref_order_ = false;
+    DevBuf<uint32_t> ref_order_csc_, ref_order_csr_;  // segments, longest first
     int scatter_finalize(bool cols, const FinalizeArgs& base);  // slabs -> dense (g,h) -> [all-reduce] -> finalize
     int rank_fused_scatter(uint32_t t);
     int finalize_cols(const FinalizeArgs& base);  // CSC side: all-reduce across shards if sharded

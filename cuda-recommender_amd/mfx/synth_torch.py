@@ -95,6 +95,27 @@ def synth_ratings_device(rows: int, cols: int, nnz: int, seed: int = 1234, devic
                 test_row=i32(ti), test_col=i32(tj), test_val=tv.contiguous(), csc_of_csr=order)
 
 
+def leading_row_block(d, nblocks: int):
+    """The first of `nblocks` nnz-balanced contiguous blocks of user rows of the device matrix `d` (the rule of
+    mfx_partition_rows), as a device dict of the same form: local CSR = a prefix of the CSR arrays, local CSC = the
+    entries of every column whose row falls in the block, in the column's own order."""
+    ptr = d["csr_row_ptr"].long()
+    total = int(ptr[-1])
+    r = int(torch.searchsorted(ptr, torch.tensor([(total + nblocks - 1) // nblocks], dtype=torch.int64, device=ptr.device))[0])
+    r = max(1, min(r, int(d["rows"])))
+    z = int(ptr[r])
+    keep = d["csc_row_idx"] < r
+    cols = int(d["cols"])
+    csc_ptr = torch.zeros(cols + 1, dtype=torch.int64, device=ptr.device)
+    csc_ptr[1:] = torch.cumsum(torch.bincount(d["csr_col_idx"][:z].long(), minlength=cols), 0)
+    tkeep = d["test_row"] < r
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    return dict(rows=r, cols=cols, csr_row_ptr=d["csr_row_ptr"][:r + 1].contiguous(), csr_col_idx=d["csr_col_idx"][:z].contiguous(),
+                csr_val=d["csr_val"][:z].contiguous(), csc_col_ptr=i32(csc_ptr), csc_row_idx=d["csc_row_idx"][keep].contiguous(),
+                csc_val=d["csc_val"][keep].contiguous(), test_row=d["test_row"][tkeep].contiguous(),
+                test_col=d["test_col"][tkeep].contiguous(), test_val=d["test_val"][tkeep].contiguous())
+
+
 def to_rating_data(d):
     """Device dict -> host RatingData (numpy), for the CPU-baseline leg and parity checks."""
     import numpy as np

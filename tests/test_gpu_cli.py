@@ -42,8 +42,9 @@ def test_mfx_train_matches_reference_log(tmp_path, solver):
 
 @pytest.mark.parametrize("solver", ["ccd", "als"])
 def test_mfx_train_cuda_and_omp_legs_agree(tmp_path, solver):
-    """`-CUDA -OMP` (scripts/doit.sh's invocation): the second leg runs the as-written schedule, both legs print
-    the reference's lines, and the driver's own golden_compare passes on W and H."""
+    """`-CUDA -OMP` (scripts/doit.sh's invocation): the second leg runs the reference-order parity modes on the GPU
+    (ccd_reforder.hip / als_exact.hip, bit-identical to the reference's CPU solver), says so in the log, does NOT
+    print a time under the OMP name, and the driver's own golden_compare passes on W and H."""
     import mfx
     g, d = load_golden("small")
     mfx.dataset.write_dataset_dir(str(tmp_path / "ds"), d)
@@ -52,7 +53,8 @@ def test_mfx_train_cuda_and_omp_legs_agree(tmp_path, solver):
     args = [exe, "-CUDA", "-OMP", "-k", str(k), "-l", repr(lam), "-t", "3", "-T", "1"] + (["-ALS"] if solver == "als" else []) + [str(tmp_path / "ds")]
     r = subprocess.run(args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert "[info] CUDA Training time:" in r.stdout and "[info] OMP Training time:" in r.stdout
+    assert "[info] CUDA Training time:" in r.stdout and "[info] reference-order GPU leg training time:" in r.stdout
+    assert "OMP Training time" not in r.stdout and "no CPU solver" in r.stdout
     # golden_compare's bar is the reference's: 10 % per entry (src/extras.cpp:218-238).  CCD++ meets it on every
     # entry; ALS entries close to zero may not (the product path solves where the reference inverts), so there the
     # check must pass or stay below 1 % of the entries
@@ -62,6 +64,12 @@ def test_mfx_train_cuda_and_omp_legs_agree(tmp_path, solver):
     finals = [float(x) for x in re.findall(r"Test RMSE = ([0-9.]+)\.", r.stdout)]
     tag = "ccd_T1" if solver == "ccd" else "als"
     assert len(finals) == 2 and all(abs(x - float(g[tag + "__final_rmse"][0])) < (1e-4 if solver == "ccd" else 3e-4) for x in finals)
+    # the second leg is the reference's arithmetic: its final RMSE is the golden one to the printed six decimals,
+    # and so is every per-iteration RMSE of its log
+    assert abs(finals[1] - float(g[tag + "__final_rmse"][0])) < 1.5e-6
+    second_log = r.stdout[r.stdout.index("reference-order leg on the GPU"):]
+    rmse2 = np.array([float(x) for x in re.findall(r"\[-INFO-\] iteration num \d+ .*RMSE=([0-9.]+)", second_log)])
+    assert rmse2.size == 3 and np.all(np.abs(rmse2 - g[tag + "__rmse"][:3]) < 1.5e-6), (rmse2, g[tag + "__rmse"])
 
 
 def test_text_ratings_to_mfx_train_matches_reference_log(tmp_path):

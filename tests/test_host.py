@@ -284,7 +284,7 @@ def test_bench_launches_its_own_workers():
     import sys
     pytest.importorskip("torch")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    for n, want in ((2, 3.0), (1, 1.0)):
+    for n, want in ((8, 36.0), (2, 3.0), (1, 1.0)):  # 8: the driver's full-node launch shape
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run", "--workload", "config5"],
                            capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr
@@ -296,3 +296,15 @@ def test_bench_launches_its_own_workers():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--no-such-flag"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0
+    # a rank that dies BEFORE it joins the collective (an OOM kill while the matrix is generated, a failed setup):
+    # the launcher supervises every child, reports which rank went, stops the ranks left waiting for it and returns
+    # that status -- within seconds, not at the driver's timeout
+    import time
+    for bad in (3, 0):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run", "--dry-run-fail-rank", str(bad)],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 3, (r.returncode, r.stderr)
+        assert f"rank {bad} exited with status 3" in r.stderr
+        assert time.time() - t0 < 120
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
