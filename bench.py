@@ -466,6 +466,11 @@ def main() -> None:
                        "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},
             "roofline": roofline, "rank_one_kernel": rank_one, "cpu_baseline": cpu_baseline, "kernels": kernels,
             "allreduce_us_per_inner_iter": (kernels["rccl_allreduce"]["avg_us"] if "rccl_allreduce" in kernels else None),
+            # host time to enqueue one outer iteration's launches (+ collectives) in the event-bracketed pass, next to the
+            # GPU time of the same iteration: while it is smaller, launch cost is hidden behind the running kernels (the
+            # sharded path launches eagerly -- no hipGraph replay around the collectives)
+            "host_enqueue_ms_per_step": (round(kernels["host_enqueue_outer_iteration"]["avg_us"] / 1e3, 3)
+                                         if "host_enqueue_outer_iteration" in kernels else None),
             "layout": layout, "test_rmse_after": round(rmse_now, 6), "gen_seconds": round(gen_s, 2), "setup_seconds": round(setup_s, 2),
         }
         print(json.dumps(out), flush=True)

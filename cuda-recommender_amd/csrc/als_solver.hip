@@ -1033,9 +1033,10 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         lrows = (uint32_t) (shard->row_hi - shard->row_lo); lcols = (uint32_t) (shard->col_hi - shard->col_lo);
         nnz_rows = R->csr_row_ptr[lrows]; nnz_cols = R->csc_col_ptr[lcols];
         global_test_nnz_ = shard->global_test_nnz;
-        MFX_TRY(gather_bounds(comm_, shard->row_lo, shard->row_hi, &row_bounds_, st_));
-        MFX_TRY(gather_bounds(comm_, shard->col_lo, shard->col_hi, &col_bounds_, st_));
-        MFX_REQUIRE(row_bounds_.back() == R->rows && col_bounds_.back() == R->cols, "ALS shards do not cover the matrix");
+        row_hi_ = (uint32_t) shard->row_hi; col_hi_ = (uint32_t) shard->col_hi;
+        // No collective in here (mfx.h, mfx_comm_agree): a rank that fails any check of its own setup must not leave
+        // the others inside one.  The block boundaries of the other ranks are gathered by the first iterate() call,
+        // which every rank reaches only after mfx_comm_agree reported that everybody's setup succeeded.
     }
     // W-half walks CSR rows with csr_val (src/ALS.cpp:132), H-half walks CSC columns
     MFX_TRY(rows_.build(lrows, nnz_rows, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, kAlsChunk, st_));
@@ -1061,13 +1062,20 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     return MFX_OK;
 }
 
-// After a half-sweep every rank holds only its own block of the factor it just solved: one
-// broadcast per rank (root = owner) makes the replica whole again.
+// After a half-sweep every rank holds only its own block of the factor it just solved: ONE grouped exchange
+// (every owner broadcasts its block inside a single ncclGroupStart / End) makes the replica whole again.
 int AlsSolver::exchange(float* X, const std::vector<int64_t>& bounds) {
-    for (int r = 0; r < comm_->nranks; ++r) {
-        const int64_t lo = bounds[r], hi = bounds[(size_t) r + 1];
-        MFX_TRY(comm_broadcast_f32(comm_, X + (size_t) lo * k_, (size_t) (hi - lo) * k_, r, st_));
-    }
+    std::vector<int64_t> elems(bounds.size());
+    for (size_t r = 0; r < bounds.size(); ++r) elems[r] = bounds[r] * (int64_t) k_;
+    return comm_allgather_blocks_f32(comm_, X, elems.data(), st_);
+}
+
+// First iterate() of a sharded solve: everyone's block boundaries.  Every rank sees the same gathered vector, so a
+// partition that is not contiguous in rank order or does not cover the matrix fails on ALL ranks alike.
+int AlsSolver::meet_shards() {
+    MFX_TRY(gather_bounds(comm_, row_lo_, row_hi_, &row_bounds_, st_));
+    MFX_TRY(gather_bounds(comm_, col_lo_, col_hi_, &col_bounds_, st_));
+    MFX_REQUIRE(row_bounds_.back() == (int64_t) m_ && col_bounds_.back() == (int64_t) n_, "ALS shards do not cover the matrix");
     return MFX_OK;
 }
 
@@ -1086,6 +1094,7 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
     MFX_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
     MFX_REQUIRE(factors_set_, "mfx_als_iterate: call mfx_als_set_factors first");
     MFX_TRY(use_device(device_));
+    if (comm_ && row_bounds_.empty() && n_iter > 0) MFX_TRY(meet_shards());
     for (int it = 0; it < n_iter; ++it) {
         MFX_HIP(hipMemsetAsync(spd_fail_.get(), 0, sizeof(uint32_t), st_));
         MFX_HIP(hipEventRecord(ev_[0], st_));

@@ -48,14 +48,15 @@ public:
 private:
     AlsSolver() = default;
     int init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx_memspace space, const mfx_als_shard* shard);
-    int exchange(float* X, const std::vector<int64_t>& bounds);  // every rank broadcasts its block of X
+    int exchange(float* X, const std::vector<int64_t>& bounds);  // every rank broadcasts its block of X (one grouped call)
+    int meet_shards();  // first iterate() of a sharded solve: gathers everyone's block boundaries (never in create)
     int device_ = 0;
     hipStream_t st_ = nullptr;
     mfx_params p_{};
     uint32_t m_ = 0, n_ = 0, k_ = 0;
     // sharded solve: this rank's row / column block and everyone's block boundaries
     mfx_comm_s* comm_ = nullptr;
-    uint32_t row_lo_ = 0, col_lo_ = 0;
+    uint32_t row_lo_ = 0, col_lo_ = 0, row_hi_ = 0, col_hi_ = 0;
     std::vector<int64_t> row_bounds_, col_bounds_;
     int64_t global_test_nnz_ = 0;
     AlsHalf rows_, cols_;

@@ -46,8 +46,12 @@ struct SegStreamDev {
     const uint32_t* segid = nullptr;           // [padded nnz] segment of every stored element (pad: 0); nullptr when the byte steps below fit
     const uint8_t* seg_delta = nullptr;        // [padded nnz] step from the previous entry of the tile's sorted order
     const uint32_t* tile_base = nullptr;       // [padded nnz / 256] segment of a tile's first sorted entry
-    unsigned long long* wgacc = nullptr;       // [workgroups][2 * panel_rows] fixed-point (g, h) slabs
-    const uint32_t* wg_lo = nullptr;           // [npanels + 1] first workgroup of every panel
+    unsigned long long* wgacc = nullptr;       // [slabs][2 * panel_rows] fixed-point (g, h) slabs
+    uint32_t scat_nwg = 0;                     // persistent workgroups of the scatter pass (one per CU, or fewer chunks)
+    const uint32_t* scat_chunk_lo = nullptr;   // [scat_nwg + 1] chunk range of every persistent workgroup
+    const uint32_t* scat_slab0 = nullptr;      // [scat_nwg] first slab of a workgroup (it writes one per panel it visits)
+    const uint32_t* slab_lo = nullptr;         // [npanels + 1] first slab of every panel (a panel's slabs are consecutive)
+    uint32_t* scat_slab_bad = nullptr;         // [slabs] a term of the slab was not representable in the fixed-point sums
     // fused finalize (LDS panels, 16-span workgroups): see fused_finalize in ccd_kernels.hip; nullptr = not available
     const uint32_t* fz_order = nullptr;        // [workgroups] dispatch slot -> chunk
     const uint32_t* fz_g0 = nullptr;           // [workgroups] first / last segment group of a chunk

@@ -20,9 +20,18 @@
 //     scale 2^36: exact for |x| < 1.3e8, resolution 1.5e-11; an fp32 sum of n such terms is off by
 //     ~6e-8 * |sum| * sqrt(n), the fixed-point one by ~1e-11 * sqrt(n)).  LDS fp32 atomics would be both
 //     non-deterministic and 4x slower (same profile: 1.39 ms vs 0.34 ms).
-// Every workgroup flushes its accumulators to its own slab; k_scatter_combine adds the slabs of a panel
-// (integers: any order gives the same bits) and converts to the dense fp32 (g, h) that the ordinary
+// A workgroup flushes its accumulators to a slab when it leaves a panel; k_scatter_combine adds the slabs of a
+// panel (integers: any order gives the same bits) and converts to the dense fp32 (g, h) that the ordinary
 // finalize / all-reduce path takes.
+//
+// (r3) PERSISTENT WORKGROUPS.  The grid is one workgroup per CU (the LDS allows no more); workgroup w owns the
+// contiguous chunk range [chunk_lo[w], chunk_lo[w+1]) of the panel-major stream and keeps a panel's slice and
+// accumulators in LDS across all of its chunks of that panel -- it reloads / flushes only where the panel changes
+// inside its range.  Round 2 launched one workgroup per 57 k-entry chunk: 2180 of them on the shard, each loading a
+// 54 KB slice, zeroing 109 KB of LDS, writing a 107 KB slab (read again by the combine) and -- alone on its CU --
+// leaving the CU idle through its own prologue and epilogue.  Now ~256 + npanels slabs instead of 2180 (the slabs
+// of a panel are still consecutive: ranges and panels are both ascending), and a wave's tile pipeline runs on
+// across chunk boundaries.
 //
 // Measured on the shard shape (k = 128): 0.51 ms (column sums, 8-byte streamed operand) / 0.66 ms (row sums,
 // 16-byte operand) per pass against 0.85 / 0.93 ms for cache panels; 244 -> 160 ms per outer iteration.  What
@@ -41,6 +50,8 @@
 // kernel, so both residual copies keep holding bit-identical values whichever kernel updates them.
 #include "ccd_kernels.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 namespace mfx {
@@ -65,7 +76,9 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
     return a - b;
 }
 
-// fp32 -> 64-bit fixed point (two's complement), scale 2^36: exact for every fp32 with |x| < 2^27.
+// fp32 -> 64-bit fixed point (two's complement), scale 2^36: |x| must stay below 2^27 (kFixedLimit; checked per
+// term, see `bad`), resolution 2^-36 (terms are truncated toward zero at that resolution; an fp32 with |x| >= 2^-12
+// converts exactly).
 // (r2: a 3-instruction conversion -- fma onto 1.5 * 2^52, integer in the low mantissa bits -- instead of this
 // 9-instruction f64 -> i64 sequence changed nothing: 339 vs 345 us on the Netflix shape, 531 vs 510 us on the
 // shard.  Neither the VALU nor the LDS atomics bound the pass: tools/ubench_ldsatomic.hip measures 0.49 clk per
@@ -73,6 +86,7 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
 __device__ __forceinline__ unsigned long long to_fixed(float x) {
     return (unsigned long long) (long long) ((double) x * 68719476736.0);
 }
+constexpr float kFixedLimit = 134217728.f;  // 2^27
 
 struct ScatterArgs {
     const uint16_t* lidx;     // [padded] local index inside the panel (pad: panel_rows)
@@ -84,7 +98,11 @@ struct ScatterArgs {
     uint32_t tiles_per_span, panel_rows, local_len;
     const void* slice_src;    // operands of the local dimension, [local_len]
     const void* global_op;    // operands of the streamed dimension, indexed by segid
-    unsigned long long* wgacc;  // [workgroups][2 * panel_rows] slabs
+    unsigned long long* wgacc;  // [slabs][2 * panel_rows]
+    const uint32_t* chunk_lo; // [workgroups + 1] chunk range of every persistent workgroup
+    const uint32_t* slab0;    // [workgroups] first slab a workgroup writes (one per panel it visits, ascending)
+    uint32_t* slab_bad;       // [slabs] != 0: some term of the slab was NaN / Inf / beyond the fixed-point range
+    uint32_t stagger;         // wave w idles w * stagger * 64 clocks before its first tile (de-phases the 16 waves of a workgroup)
     int add;
 };
 
@@ -126,28 +144,10 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     S* __restrict__ slice = reinterpret_cast<S*>(lds_raw);
     unsigned long long* __restrict__ acc = reinterpret_cast<unsigned long long*>(lds_raw + scat_slice_bytes<MODE>(a.panel_rows));
+    __shared__ uint32_t bad_any;
     const uint32_t pr = a.panel_rows;
-    const uint32_t panel = a.wg_panel[blockIdx.x];
-    const uint32_t gbase = panel * pr;
-    const uint32_t cnt = a.local_len - gbase < pr ? a.local_len - gbase : pr;
-    if constexpr (TR::kSlice) {
-        const S* __restrict__ src = static_cast<const S*>(a.slice_src);
-        // slots cnt .. pr (the tail of a short last panel and the padding slot) hold zeros: padding entries
-        // then keep their stored 0 and contribute exact zeros
-        for (uint32_t i = threadIdx.x; i <= pr; i += kScatBlock) slice[i] = i < cnt ? src[gbase + i] : S{};
-    }
-    if constexpr (TR::kAcc)
-        for (uint32_t i = threadIdx.x; i < 2 * (pr + 1); i += kScatBlock) acc[i] = 0ull;
-    __syncthreads();
-
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t span = blockIdx.x * (kScatBlock / 64) + (threadIdx.x >> 6);
-    const uint64_t start = (uint64_t) span * a.tiles_per_span * 256;
-    const u16x4* __restrict__ l4 = reinterpret_cast<const u16x4*>(a.lidx + start) + lane;
-    const u32x4* __restrict__ s4 = IDS32 ? reinterpret_cast<const u32x4*>(a.segid + start) + lane : nullptr;
-    const uint32_t* __restrict__ d1 = IDS32 ? nullptr : reinterpret_cast<const uint32_t*>(a.seg_delta + start) + lane;
-    const uint32_t* __restrict__ tb = IDS32 ? nullptr : a.tile_base + start / 256;
-    f32x4* __restrict__ v4 = reinterpret_cast<f32x4*>(a.val + start) + lane;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nt = a.tiles_per_span;
     const G* __restrict__ gop = static_cast<const G*>(a.global_op);
     // Inside every 256-entry tile the builder stores the row-sorted entries TRANSPOSED: lane l's four elements are
     // sorted entries l, 64 + l, 128 + l, 192 + l of the tile.  The streams keep their 16-byte-per-lane loads, and
@@ -158,29 +158,31 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     // Schedule: two statically named register sets (no register is rotated through a move: a move of a register
     // that is still in flight is a wait); per tile the four gathers go out back to back, then the stream loads of
     // the next tile, then the tile is computed.  Straight-line body, no branch (a branch merges two wait counts
-    // into the smaller one); the loads past the span's end are clamped re-reads.  The sched_barriers pin the issue
+    // into the smaller one); the loads past the run's end are clamped re-reads.  The sched_barriers pin the issue
     // order -- left to itself the compiler sinks every gather to its use behind the LDS atomics of the previous
     // element and waits vmcnt(0) four times per tile.
     // Segment ids: IDS32 streams them (4 B per entry); otherwise a tile carries one byte per entry -- the step from
     // the previous entry of its sorted order -- and one base id: lane l's dword holds the steps of sorted entries
     // l, 64 + l, 128 + l, 192 + l, so two packed 16-bit prefix scans over the lanes plus the group totals give the
     // four ids (a tile spans at most 255 * 256 ids).  ~30 VALU instructions per tile for 3 B per entry less.
-    struct Tile { u16x4 l; u32x4 s; uint32_t d, base; f32x4 v; };
-    const uint32_t nt = a.tiles_per_span;
-    auto stream = [&](uint32_t t) {
-        const uint32_t tc = t < nt ? t : nt - 1;
+    struct Tile { u16x4 l; u32x4 s; uint32_t d, base; f32x4 v; uint32_t tile; };
+    // tile index (in units of 256 stored entries) of this wave's q-th tile of a run of chunks that starts at chunk
+    // `c0`: wave i owns span i of every chunk, i.e. tiles ((c0 + q / nt) * 16 + i) * nt + q % nt
+    auto stream = [&](uint32_t tile) {
         Tile x;
+        x.tile = tile;
+        const uint64_t e0 = (uint64_t) tile * 256;
         // issue order pinned: ids first, values last.  The wait before a tile's gathers then never has to
         // cover the value load -- nor, on the loop's back edge, the previous tile's store behind it.
         if constexpr (IDS32) {
-            x.s = __builtin_nontemporal_load(s4 + tc * 64);
+            x.s = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.segid + e0) + lane);
         } else {
-            x.d = __builtin_nontemporal_load(d1 + tc * 64);
-            x.base = tb[tc];
+            x.d = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.seg_delta + e0) + lane);
+            x.base = a.tile_base[tile];
         }
-        x.l = __builtin_nontemporal_load(l4 + tc * 64);
+        x.l = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(a.lidx + e0) + lane);
         __builtin_amdgcn_sched_barrier(0);
-        x.v = __builtin_nontemporal_load(v4 + tc * 64);
+        x.v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.val + e0) + lane);
         return x;
     };
     auto ids = [&](const Tile& x) {
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
         for (int e = 0; e < 4; ++e) r.g[e] = gop[id[e]];  // ascending inside a panel: a few cache lines per wave
         return r;
     };
-    auto compute = [&](const Tile& x, const Gath& gp, uint32_t t) {
+    bool bad = false;  // a term that the fixed-point accumulators cannot hold (NaN, Inf, |x| >= 2^27)
+    auto compute = [&](const Tile& x, const Gath& gp) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -234,48 +237,101 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
                 gc = 0.f; hc = 0.f;
             }
             if constexpr (TR::kAcc) {
+                bad |= !(__builtin_fabsf(gc) < kFixedLimit) | !(hc < kFixedLimit);  // (NaN compares false)
                 atomicAdd(&acc[2 * l], to_fixed(gc));
                 atomicAdd(&acc[2 * l + 1], to_fixed(hc));
             }
         }
-        if constexpr (TR::kWrite) __builtin_nontemporal_store(o, v4 + t * 64);
+        if constexpr (TR::kWrite) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(a.val + (uint64_t) x.tile * 256) + lane);
     };
-    Tile A = stream(0), B;
-    Gath ga, gb;
-    for (uint32_t t = 0; t < nt; t += 2) {
-        ga = gather(A);
-        B = stream(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(A, ga, t);
-        __builtin_amdgcn_sched_barrier(0);
-        gb = gather(B);
-        A = stream(t + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(B, gb, t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (TR::kAcc) {
+
+    const uint32_t c_end = a.chunk_lo[blockIdx.x + 1];
+    uint32_t chunk = a.chunk_lo[blockIdx.x];
+    uint32_t slab = a.slab0[blockIdx.x];
+    if (threadIdx.x == 0) bad_any = 0;
+    while (chunk < c_end) {
+        // ---- a run: the chunks of ONE panel inside this workgroup's range
+        const uint32_t panel = a.wg_panel[chunk];
+        uint32_t run_end = chunk + 1;
+        while (run_end < c_end && a.wg_panel[run_end] == panel) ++run_end;
+        const uint32_t gbase = panel * pr;
+        const uint32_t cnt = a.local_len - gbase < pr ? a.local_len - gbase : pr;
+        if constexpr (TR::kSlice) {
+            const S* __restrict__ src = static_cast<const S*>(a.slice_src);
+            // slots cnt .. pr (the tail of a short last panel and the padding slot) hold zeros: padding entries
+            // then keep their stored 0 and contribute exact zeros
+            for (uint32_t i = threadIdx.x; i <= pr; i += kScatBlock) slice[i] = i < cnt ? src[gbase + i] : S{};
+        }
+        if constexpr (TR::kAcc)
+            for (uint32_t i = threadIdx.x; i < 2 * (pr + 1); i += kScatBlock) acc[i] = 0ull;
         __syncthreads();
-        unsigned long long* __restrict__ dst = a.wgacc + (size_t) blockIdx.x * 2 * pr;
-        for (uint32_t i = threadIdx.x; i < 2 * pr; i += kScatBlock) dst[i] = acc[i];
+
+        // this wave's tiles of the run, in order: span `wave` of chunk, chunk + 1, ...; a cursor on the scalar unit
+        // (tile index in units of 256 stored entries).  Past the end it stays on the last tile: a clamped re-read
+        // that is never computed.
+        const uint32_t Q = (run_end - chunk) * nt;  // even: nt is
+        uint32_t cur = (chunk * (kScatBlock / 64) + wave) * nt, t_in = 0, left = Q;
+        auto next_tile = [&]() {
+            const uint32_t r = cur;
+            if (left > 1) {
+                --left; ++cur;
+                if (++t_in == nt) { t_in = 0; cur += (kScatBlock / 64 - 1) * nt; }
+            }
+            return r;
+        };
+        for (uint32_t i = 0; i < wave * a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+        Tile A = stream(next_tile()), B;
+        Gath ga, gb;
+        for (uint32_t q = 0; q < Q; q += 2) {
+            ga = gather(A);
+            B = stream(next_tile());
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A, ga);
+            __builtin_amdgcn_sched_barrier(0);
+            gb = gather(B);
+            A = stream(next_tile());
+            __builtin_amdgcn_sched_barrier(0);
+            compute(B, gb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (TR::kAcc) {
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) bad_any = 1;
+            bad = false;
+        }
+        __syncthreads();  // every wave has left the panel: its sums are complete, its slice is dead
+        if constexpr (TR::kAcc) {
+            unsigned long long* __restrict__ dst = a.wgacc + (size_t) slab * 2 * pr;
+            for (uint32_t i = threadIdx.x; i < 2 * pr; i += kScatBlock) dst[i] = acc[i];
+            if (threadIdx.x == 0) { a.slab_bad[slab] = bad_any; bad_any = 0; }
+            ++slab;
+            // (the same thread zeroes exactly the words it just copied, at the top of the next run: no barrier needed
+            // between the two; the one above orders the slice reload behind every wave's last read)
+        }
+        chunk = run_end;
     }
 }
 
-// gh[c] = g, gh[G + c] = h of local-dimension index c: the slabs of its panel's workgroups added as integers
-__global__ __launch_bounds__(256) void k_scatter_combine(uint32_t G, uint32_t pr, const uint32_t* __restrict__ wg_lo,
-                                                         const unsigned long long* __restrict__ wgacc, float* __restrict__ gh) {
+// gh[c] = g, gh[G + c] = h of local-dimension index c: the slabs of its panel added as integers.  A slab that met a
+// term its fixed-point accumulators cannot hold (NaN, Inf, |x| >= 2^27: a diverging solve) poisons the panel's sums
+// with NaN -- the flat path and the reference propagate non-finite values the same way -- instead of delivering
+// finite but wrong numbers.
+__global__ __launch_bounds__(256) void k_scatter_combine(uint32_t G, uint32_t pr, const uint32_t* __restrict__ slab_lo,
+                                                         const unsigned long long* __restrict__ wgacc,
+                                                         const uint32_t* __restrict__ slab_bad, float* __restrict__ gh) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= G) return;
     const uint32_t p = c / pr, l = c - p * pr;
     unsigned long long g = 0, h = 0;
-    for (uint32_t w = wg_lo[p]; w < wg_lo[p + 1]; ++w) {
+    uint32_t bad = 0;
+    for (uint32_t w = slab_lo[p]; w < slab_lo[p + 1]; ++w) {
         const unsigned long long* s = wgacc + (size_t) w * 2 * pr + 2 * l;
         g += s[0];
         h += s[1];
+        bad |= slab_bad[w];
     }
     constexpr double inv = 1.0 / 68719476736.0;
-    gh[c] = (float) ((double) (long long) g * inv);
-    gh[G + c] = (float) ((double) (long long) h * inv);
+    gh[c] = bad ? __builtin_nanf("") : (float) ((double) (long long) g * inv);
+    gh[G + c] = bad ? __builtin_nanf("") : (float) ((double) (long long) h * inv);
 }
 
 template <int MODE, bool IDS32>
@@ -293,7 +349,7 @@ int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, hipStream_t st
             if (dev >= 0 && dev < 64) set_bytes[dev] = lds;
         }
     }
-    hipLaunchKernelGGL((k_scatter<MODE, IDS32>), dim3(s.nspans / s.spans_per_wg), dim3(kScatBlock), lds, st, a);
+    hipLaunchKernelGGL((k_scatter<MODE, IDS32>), dim3(s.scat_nwg), dim3(kScatBlock), lds, st, a);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
@@ -305,7 +361,11 @@ int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_sr
     ScatterArgs a;
     a.lidx = s.idx16; a.segid = s.segid; a.seg_delta = s.seg_delta; a.tile_base = s.tile_base; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
     a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;
+    a.chunk_lo = s.scat_chunk_lo; a.slab0 = s.scat_slab0; a.slab_bad = s.scat_slab_bad;
     a.add = add;
+    a.stagger = 0;
+    if (const char* e = std::getenv("MFX_SCATTER_STAGGER")) a.stagger = (uint32_t) std::max(0, std::atoi(e));
+    MFX_REQUIRE(s.scat_nwg > 0 && s.scat_chunk_lo && s.scat_slab0 && s.slab_lo && s.scat_slab_bad, "launch_scatter: the layout carries no workgroup ranges");
     MFX_REQUIRE(s.segid || (s.seg_delta && s.tile_base), "launch_scatter: the layout carries no segment ids");
     const bool ids32 = s.seg_delta == nullptr;
     switch (mode) {
@@ -319,7 +379,7 @@ int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_sr
 
 int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st) {
     if (s.gather_len == 0) return MFX_OK;
-    hipLaunchKernelGGL(k_scatter_combine, dim3((s.gather_len + 255) / 256), dim3(256), 0, st, s.gather_len, s.panel_rows, s.wg_lo, s.wgacc, gh);
+    hipLaunchKernelGGL(k_scatter_combine, dim3((s.gather_len + 255) / 256), dim3(256), 0, st, s.gather_len, s.panel_rows, s.slab_lo, s.wgacc, s.scat_slab_bad, gh);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }

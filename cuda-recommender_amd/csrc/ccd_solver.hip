@@ -235,15 +235,35 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     MFX_TRY(wg_panel_.alloc(wg_panel.empty() ? 1 : wg_panel.size()));
     MFX_TRY(wg_panel_.upload(wg_panel.data(), wg_panel.size(), MFX_HOST, st));
     MFX_TRY(panel_end_dev_.alloc(P)); MFX_TRY(panel_end_dev_.upload(real_end.data(), P, MFX_HOST, st));
-    std::vector<uint32_t> wg_lo;
-    if (opt.scatter) {  // slabs of the workgroups + first workgroup of every panel; no partials / carries
+    uint32_t scat_nwg = 0;
+    if (opt.scatter) {  // persistent workgroups: chunk ranges, the slabs they write, first slab of every panel; no partials / carries
         MFX_REQUIRE(opt.panel_rows && lds && spans_per_wg == 16, "scatter layout needs LDS panels and 16-span workgroups");
-        const uint32_t nwg = nspans / spans_per_wg;
-        wg_lo.assign((size_t) P + 1, nwg);
-        for (uint32_t w = nwg; w-- > 0;) wg_lo[wg_panel[w]] = w;
-        for (uint32_t p = P; p-- > 0;) if (wg_lo[p] > wg_lo[p + 1]) wg_lo[p] = wg_lo[p + 1];  // a panel without workgroups
-        MFX_TRY(wg_lo_.alloc(wg_lo.size())); MFX_TRY(wg_lo_.upload(wg_lo.data(), wg_lo.size(), MFX_HOST, st));
-        MFX_TRY(wgacc_.alloc((size_t) nwg * 2 * opt.panel_rows));
+        const uint32_t nchunks = nspans / spans_per_wg;
+        int dev = 0, cus = 0;
+        MFX_HIP(hipGetDevice(&dev));
+        MFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        // one workgroup per CU (a workgroup takes the whole LDS); MFX_SCATTER_WGS overrides for experiments and tests
+        uint32_t want = cus > 0 ? (uint32_t) cus : 256u;
+        if (const char* e = std::getenv("MFX_SCATTER_WGS")) { const int v = std::atoi(e); if (v > 0) want = (uint32_t) v; }
+        scat_nwg = std::max(1u, std::min(want, nchunks));
+        std::vector<uint32_t> chunk_lo((size_t) scat_nwg + 1), slab0(scat_nwg), slab_lo((size_t) P + 1, 0u);
+        for (uint32_t w = 0; w <= scat_nwg; ++w) chunk_lo[w] = (uint32_t) ((uint64_t) nchunks * w / scat_nwg);
+        uint32_t nslabs = 0;
+        std::vector<uint32_t> slabs_of_panel(P, 0u);
+        for (uint32_t w = 0; w < scat_nwg; ++w) {
+            slab0[w] = nslabs;
+            for (uint32_t c = chunk_lo[w]; c < chunk_lo[w + 1]; ++c)
+                if (c == chunk_lo[w] || wg_panel[c] != wg_panel[c - 1]) { ++nslabs; ++slabs_of_panel[wg_panel[c]]; }
+        }
+        // ranges and panels both ascend, so the slabs of a panel are consecutive in the numbering above
+        for (uint32_t p = 0; p < P; ++p) slab_lo[p + 1] = slab_lo[p] + slabs_of_panel[p];
+        MFX_REQUIRE(slab_lo[P] == nslabs, "scatter layout: slab bookkeeping is inconsistent (%u vs %u)", slab_lo[P], nslabs);
+        MFX_TRY(slab_lo_.alloc(slab_lo.size())); MFX_TRY(slab_lo_.upload(slab_lo.data(), slab_lo.size(), MFX_HOST, st));
+        MFX_TRY(scat_chunk_lo_.alloc(chunk_lo.size())); MFX_TRY(scat_chunk_lo_.upload(chunk_lo.data(), chunk_lo.size(), MFX_HOST, st));
+        MFX_TRY(scat_slab0_.alloc(slab0.size())); MFX_TRY(scat_slab0_.upload(slab0.data(), slab0.size(), MFX_HOST, st));
+        MFX_TRY(scat_slab_bad_.alloc_zero(std::max(1u, nslabs), st));
+        MFX_TRY(wgacc_.alloc((size_t) std::max(1u, nslabs) * 2 * opt.panel_rows));
+        MFX_HIP(hipStreamSynchronize(st));  // the host vectors behind the uploads
     } else {
         MFX_TRY(part_.alloc_zero(nne ? nne : 1, st));
         MFX_TRY(carry_.alloc_zero(nspans, st));
@@ -267,7 +287,8 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     view.seg_of_rank = seg_of_rank_.get(); view.max_wg_ranks = max_wg_ranks;
     view.wg_panel = wg_panel_.get(); view.perm = nullptr; view.part = part_.get();
     view.carry = carry_.get();
-    view.scatter = opt.scatter; view.segid = segid_.get(); view.seg_delta = seg_delta_.get(); view.tile_base = tile_base_.get(); view.wgacc = wgacc_.get(); view.wg_lo = wg_lo_.get();
+    view.scatter = opt.scatter; view.segid = segid_.get(); view.seg_delta = seg_delta_.get(); view.tile_base = tile_base_.get(); view.wgacc = wgacc_.get(); view.slab_lo = slab_lo_.get();
+    view.scat_nwg = scat_nwg; view.scat_chunk_lo = scat_chunk_lo_.get(); view.scat_slab0 = scat_slab0_.get(); view.scat_slab_bad = scat_slab_bad_.get();
     *done = true;
     return MFX_OK;
 }
@@ -480,7 +501,7 @@ static const char* kKernelNames[KernelProfiler::K_COUNT] = {
     "ccd_fused_csc_pass", "ccd_fused_csr_pass", "ccd_flat_sweep", "ccd_flat_resid", "ccd_finalize",
     "ccd_combine_dense", "ccd_pack", "test_rmse", "rccl_allreduce", "ccd_wave_sweep", "ccd_wave_resid",
     "ccd_scatter_v_pass", "ccd_scatter_u_pass", "ccd_scatter_sweep", "ccd_scatter_resid", "ccd_scatter_combine",
-    "ccd_ref_order_sweep"};
+    "ccd_ref_order_sweep", "host_enqueue_outer_iteration"};
 
 const char* KernelProfiler::name(int id) { return id >= 0 && id < K_COUNT ? kKernelNames[id] : "?"; }
 
@@ -1080,7 +1101,12 @@ int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
         double before[KernelProfiler::K_COUNT];
         for (int i = 0; i < KernelProfiler::K_COUNT; ++i) before[i] = prof_.seconds[i];
         MFX_HIP(hipEventRecord(ev_[0], st_));
+        const auto host_t0 = std::chrono::steady_clock::now();
         MFX_TRY(enqueue_outer_iteration(oiter));
+        if (prof_.enabled()) {  // host time to ENQUEUE the iteration's launches (and collectives): hidden as long as it stays below the GPU time
+            prof_.seconds[KernelProfiler::K_HOST_ENQUEUE] += std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
+            prof_.launches[KernelProfiler::K_HOST_ENQUEUE] += 1;
+        }
         MFX_HIP(hipEventRecord(ev_[1], st_));
         double rmse = 0.0;
         MFX_HIP(hipEventRecord(ev_[2], st_));

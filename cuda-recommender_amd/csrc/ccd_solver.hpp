@@ -45,7 +45,7 @@ private:
     DevBuf<float2> part_, carry_;
     DevBuf<uint32_t> rank_code_;
     DevBuf<uint16_t> idx16_;
-    DevBuf<uint32_t> segid_, wg_lo_, tile_base_;  // scatter layout
+    DevBuf<uint32_t> segid_, slab_lo_, tile_base_, scat_chunk_lo_, scat_slab0_, scat_slab_bad_;  // scatter layout
     DevBuf<uint8_t> seg_delta_;
     DevBuf<unsigned long long> wgacc_;
     // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
@@ -71,7 +71,7 @@ public:
     void reset_totals();
     static const char* name(int id);
     enum { K_FCSC = 0, K_FCSR, K_SWEEP, K_RESID, K_FINALIZE, K_COMBINE, K_PACK, K_RMSE, K_ALLREDUCE,
-           K_SWEEP_WAVE, K_RESID_WAVE, K_SCAT_V, K_SCAT_U, K_SCAT_SWEEP, K_SCAT_RESID, K_SCAT_COMBINE, K_SWEEP_REF, K_COUNT };
+           K_SWEEP_WAVE, K_RESID_WAVE, K_SCAT_V, K_SCAT_U, K_SCAT_SWEEP, K_SCAT_RESID, K_SCAT_COMBINE, K_SWEEP_REF, K_HOST_ENQUEUE, K_COUNT };
     double seconds[K_COUNT] = {};
     int64_t launches[K_COUNT] = {};
 

@@ -20,6 +20,8 @@ struct RcclApi {
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -55,6 +57,8 @@ RcclApi& api() {
         a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.handle, "ncclCommAbort"));  // optional
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
         a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(sym("ncclBroadcast"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
     });
     return a;
@@ -347,6 +351,41 @@ int comm_broadcast_f32(mfx_comm_s* c, float* buf, size_t count, int root, hipStr
         return MFX_OK;
     }
     MFX_NCCL(api().Broadcast(buf, buf, count, ncclFloat32, root, static_cast<ncclComm_t>(c->nccl), st));
+    return MFX_OK;
+}
+
+// Every rank r owns elements [bounds[r], bounds[r+1]) of the replicated buffer `buf` and holds fresh values
+// there; afterwards every rank holds all blocks.  RCCL: the nranks broadcasts are ONE group call (one launch,
+// all roots progress together -- not nranks serial collectives); blocks may have different sizes, which is why
+// this is not an ncclAllGather.  Loopback: every rank stages its block, one rendezvous, everyone reads.
+int comm_allgather_blocks_f32(mfx_comm_s* c, float* buf, const int64_t* bounds, hipStream_t st) {
+    if (c->local) {
+        LocalGroup* g = c->local;
+        MFX_HIP_OR_ABORT(g, hipStreamSynchronize(st));
+        const size_t mine = (size_t) (bounds[c->rank + 1] - bounds[c->rank]) * sizeof(float);
+        g->slots[c->rank].resize(mine);
+        if (mine) MFX_HIP_OR_ABORT(g, hipMemcpy(g->slots[c->rank].data(), buf + bounds[c->rank], mine, hipMemcpyDeviceToHost));
+        if (!rendezvous(g, [] {})) return aborted_error();  // every block is staged
+        for (int r = 0; r < g->nranks; ++r) {
+            const size_t bytes = (size_t) (bounds[r + 1] - bounds[r]) * sizeof(float);
+            if (r == c->rank || bytes == 0) continue;
+            if (g->slots[r].size() != bytes) { abort_group(g); return fail(MFX_ERR_COMM, "loopback all-gather: rank %d staged %zu bytes, expected %zu", r, g->slots[r].size(), bytes); }
+            MFX_HIP_OR_ABORT(g, hipMemcpy(buf + bounds[r], g->slots[r].data(), bytes, hipMemcpyHostToDevice));
+        }
+        if (!rendezvous(g, [] {})) return aborted_error();  // nobody restages before everyone has read
+        return MFX_OK;
+    }
+    MFX_NCCL(api().GroupStart());
+    for (int r = 0; r < c->nranks; ++r) {
+        const size_t cnt = (size_t) (bounds[r + 1] - bounds[r]);
+        if (cnt == 0) continue;
+        const ncclResult_t rc = api().Broadcast(buf + bounds[r], buf + bounds[r], cnt, ncclFloat32, r, static_cast<ncclComm_t>(c->nccl), st);
+        if (rc != ncclSuccess) {
+            (void) api().GroupEnd();
+            return fail(MFX_ERR_COMM, "ncclBroadcast (grouped, root %d) failed: %s", r, api().GetErrorString ? api().GetErrorString(rc) : "?");
+        }
+    }
+    MFX_NCCL(api().GroupEnd());
     return MFX_OK;
 }
 }  // namespace mfx

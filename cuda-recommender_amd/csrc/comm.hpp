@@ -29,4 +29,7 @@ int comm_allreduce_f32(mfx_comm_s* c, float* buf, size_t count, hipStream_t st);
 int comm_allreduce_f64(mfx_comm_s* c, double* buf, size_t count, hipStream_t st);
 // In-place broadcast of `count` floats from rank `root`.
 int comm_broadcast_f32(mfx_comm_s* c, float* buf, size_t count, int root, hipStream_t st);
+// Rank r holds fresh values of elements [bounds[r], bounds[r+1]) of the replicated `buf`; afterwards everyone holds
+// every block.  One grouped call on RCCL (blocks may differ in size).
+int comm_allgather_blocks_f32(mfx_comm_s* c, float* buf, const int64_t* bounds, hipStream_t st);
 }  // namespace mfx

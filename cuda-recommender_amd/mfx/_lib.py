@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("MFX_LIB_PATH") or os.path.join(_PKG, "libmfx.so")  # 
 
 MFX_HOST, MFX_DEVICE = 0, 1
 MFX_COMM_ID_BYTES = 128
+MFX_VERSION = 2  # include/mfx.h
 
 u32p = C.POINTER(C.c_uint32)
 f32p = C.POINTER(C.c_float)
@@ -175,6 +176,12 @@ def lib() -> C.CDLL:
             raise MfxError("two HIP runtimes are mapped into this process (" + ", ".join(two) + "): libmfx "
                            "would not see the other runtime's device memory; import torch before mfx, or "
                            "set MFX_HIP_RUNTIME=system in processes that never load torch")
+        _LIB.mfx_version.restype = C.c_int
+        if _LIB.mfx_version() != MFX_VERSION:  # struct layouts / argument lists of another revision: never call into it
+            got = _LIB.mfx_version()
+            _LIB = None
+            raise MfxError(f"{LIB_PATH} speaks ABI revision {got}, this binding revision {MFX_VERSION} "
+                           f"(include/mfx.h MFX_VERSION): rebuild with `make -C {_PKG} lib`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(_LIB, name)  # AttributeError here == the .so does not export the ABI
             fn.restype = res

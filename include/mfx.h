@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define MFX_VERSION 1
+/* ABI revision: bumped whenever a struct layout or an entry point's argument list changes (2: mfx_params grew the
+ * opt-in extension fields and mfx_als_half a `variant` argument; kernel_variant -1).  A binding must compare it
+ * with mfx_version() before its first call -- mfx/_lib.py does. */
+#define MFX_VERSION 2
 
 typedef enum mfx_status {
     MFX_OK = 0,
@@ -81,7 +84,11 @@ typedef struct mfx_params {
                                   1 = fused passes (default; same arithmetic, fewer bytes).
                                   ALS: 0 = as written (explicit Cholesky inverse in the reference's operation
                                   order, bit-identical to src/ALS.cpp), 1 = MFMA Gramian + Cholesky solve */
-    int32_t kernel_variant;    /* 0 = wave-per-segment kernels (schedule 0 only), 1 = flat-stream kernels (default),
+    int32_t kernel_variant;    /* -1 = REFERENCE-ORDER parity mode (schedule 0 only, single GPU): every rank-one sum is added strictly
+                                  left to right in unfused fp32 exactly like src/CCD.cpp:6-16 -- W, H and both residual copies come out
+                                  bit-identical to the reference's CPU solver (csrc/ccd_reforder.hip; the CCD++ counterpart of ALS
+                                  schedule 0); ~5x slower than the default path;
+                                  0 = wave-per-segment kernels (schedule 0 only), 1 = flat-stream kernels (default),
                                   2 = force the scatter layout (csrc/ccd_scatter.hip), which hyper-sparse shapes
                                   get on their own: < 8 entries per (LDS panel, row / column) pair;
                                   3 = the same with explicit 32-bit segment ids in the stream (what a layout
@@ -195,7 +202,8 @@ int mfx_als_create(mfx_als_t* out, const mfx_csx* R, const mfx_coo* T, const mfx
                    mfx_memspace space);
 /* Multi-GPU ALS (SURVEY.md 8e "ALS", 8f N4): rank g owns user rows [row_lo,row_hi) for the W-half
  * and item columns [col_lo,col_hi) for the H-half; W and H are replicated and every half ends with
- * one broadcast per rank of its freshly solved block.  R->rows / R->cols are the GLOBAL sizes;
+ * ONE grouped exchange in which every rank broadcasts its freshly solved block.  Create itself runs no collective:
+ * the other ranks' block boundaries are gathered by the first mfx_als_iterate, i.e. after mfx_comm_agree.  R->rows / R->cols are the GLOBAL sizes;
  * csr_* describe the local rows (row_ptr rebased to 0, GLOBAL column indices), csc_* the local
  * columns (col_ptr rebased to 0, GLOBAL row indices); R->nnz is ignored (each orientation's count
  * is the last entry of its pointer array).  T holds the test ratings of the local rows with GLOBAL
@@ -220,7 +228,8 @@ int mfx_als_destroy(mfx_als_t s);
  * ---------------------------------------------------------------------------------- */
 /* RankOneUpdate_v_kernel / _u_kernel (cuda_src/CCD_CUDA.cu:24-58) == the sweep of
  * src/CCD.cpp:110-113: out[c] = sum(vec[idx]*val) / (lambda*|Omega_c| + sum(vec[idx]^2)),
- * 0 for an empty segment.  variant: 0 = wave-per-segment kernel, 1 = flat-stream kernel gathering
+ * 0 for an empty segment.  variant: -1 = the reference's own summation order (sequential fp32, bit-identical to
+ * the CPU reference), 0 = wave-per-segment kernel, 1 = flat-stream kernel gathering
  * from L2, 2 = flat-stream kernel with LDS panels (size chosen), >= 16 = LDS panels of `variant`
  * gathered entries, <= -16 = cache panels of `-variant` entries (test hooks: force many panels on
  * small inputs). */

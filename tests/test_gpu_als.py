@@ -149,7 +149,7 @@ def test_als_rank_limit_is_an_error(mfx):
 @pytest.mark.parametrize("nranks,k", [(2, 16), (3, 40)])
 def test_sharded_als_multi_rank_loopback(mfx, orc, nranks, k):
     """Multi-GPU ALS: rank g solves its user rows in the W-half and its item columns
-    in the H-half, each half ends with one broadcast per rank.  Ranks = threads of this process on
+    in the H-half, each half ends with one grouped exchange of the blocks.  Ranks = threads of this process on
     one GPU (loopback communicator); result must match the unsharded oracle AND the unsharded GPU solve."""
     import threading
     d = mfx.dataset.synth_ratings(2500, 700, 90_000, seed=77, skew=1.0, test_frac=0.02, empty_row_frac=0.02)
@@ -181,6 +181,58 @@ def test_sharded_als_multi_rank_loopback(mfx, orc, nranks, k):
         assert np.array_equal(W.view(np.uint32), W1.view(np.uint32)) and np.array_equal(H.view(np.uint32), H1.view(np.uint32))
         assert np.all(np.abs(np.array(rm) - rmse_ref) < 1e-4)
         assert relerr(W, Wr) < 5e-3 and relerr(H, Hr) < 5e-3
+
+
+def test_failing_als_shard_does_not_strand_the_others(mfx):
+    """mfx_als_create_sharded runs NO collective (the block boundaries of the other ranks are gathered by the first
+    iterate, after mfx_comm_agree): a rank whose create fails -- here an unsupported rank k on rank 1 -- leaves the
+    others with a finished create, everybody learns the worst status through agree() and nobody iterates.  A
+    partition that does not tile the matrix is reported by EVERY rank's first iterate alike (all ranks see the same
+    gathered boundaries), so nobody is left inside the exchange either."""
+    import threading
+    d = mfx.dataset.synth_ratings(1200, 500, 40_000, seed=78, skew=1.0, test_frac=0.02)
+    nranks, k = 3, 8
+    rb, cb = mfx.partition_rows(d, nranks), mfx.partition_cols(d, nranks)
+    seen = [None] * nranks
+
+    def setup(r):
+        comm = mfx.Comm(None, r, nranks, 0, local_group=7101)
+        status = 0
+        try:
+            sv = mfx.AlsSolver(d, None, _p(mfx, 129 if r == 1 else k, 0.05, 1), comm=comm,
+                               row_range=(int(rb[r]), int(rb[r + 1])), col_range=(int(cb[r]), int(cb[r + 1])))
+            sv.close()
+        except mfx.MfxError:
+            status = -1
+        seen[r] = comm.agree(status)
+        comm.close()
+
+    th = [threading.Thread(target=setup, args=(r,)) for r in range(nranks)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not any(x.is_alive() for x in th) and seen == [-1, -1, -1], seen
+
+    res = [None] * nranks
+    H0 = mfx.initial_col(d.cols, k)
+
+    def run(r):
+        comm = mfx.Comm(None, r, nranks, 0, local_group=7102)
+        rows = (int(rb[r]), int(rb[r + 1]) - (5 if r == 0 else 0))  # rank 0 stops five rows short: a hole in the partition
+        sv = mfx.AlsSolver(d, None, _p(mfx, k, 0.05, 1), comm=comm, row_range=rows, col_range=(int(cb[r]), int(cb[r + 1])))
+        sv.set_factors(H0.copy())
+        assert comm.agree(0) == 0
+        try:
+            sv.iterate(1)
+            res[r] = "finished"
+        except mfx.MfxError as e:
+            res[r] = "error: " + str(e)
+        sv.close(); comm.close()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
+    [x.start() for x in th]
+    [x.join(timeout=120) for x in th]
+    assert not any(x.is_alive() for x in th), res
+    assert all(isinstance(x, str) and "not contiguous" in x for x in res), res
 
 
 def _solve_f64(ptr, idx, val, X, k, lam):

@@ -206,6 +206,51 @@ def test_scatter_layout_on_golden(mfx, name, kw):
         assert np.max(np.abs(csc - g["ccd_T1__csc_val_final"])) < 2e-4 and np.max(np.abs(csr - g["ccd_T1__csr_val_final"])) < 2e-4
 
 
+@pytest.mark.parametrize("wgs", ["1", "2", "3", "7", "64", "100000"])
+def test_scatter_persistent_workgroup_ranges(mfx, orc, monkeypatch, wgs):
+    """The scatter pass runs persistent workgroups over contiguous chunk ranges of the panel-major stream
+    (ccd_scatter.hip); a range may start and end inside a panel, hold several whole panels, or be a single chunk.
+    MFX_SCATTER_WGS pins the workgroup count (default: one per CU), so 1 = one workgroup walks every panel, 2 / 3 / 7
+    = ranges that split panels at odd places, 100000 = one workgroup per chunk (round 2's launch shape).  The
+    fixed-point sums make the result independent of how the chunks are grouped: factors and residual copies must be
+    BIT-IDENTICAL across all of them, and match the oracle."""
+    d = mfx.dataset.synth_ratings(3000, 2500, 60_000, seed=31, skew=0.6, test_frac=0.02, empty_row_frac=0.02, empty_col_frac=0.02)
+    kw = dict(kernel_variant=2, panel_rows=200, tiles_per_span=2)  # 13 / 15 panels, a few chunks each
+    monkeypatch.setenv("MFX_SCATTER_WGS", "100000")
+    ref = _check(mfx, orc, d, 3, t=2, T=2, **kw)
+    monkeypatch.setenv("MFX_SCATTER_WGS", wgs)
+    got = _check(mfx, orc, d, 3, t=2, T=2, **kw)
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(ref, got))
+
+
+def test_scatter_non_finite_terms_are_not_silently_wrong(mfx):
+    """the scatter pass accumulates in 64-bit fixed point, which cannot hold NaN / Inf / |x| >= 2^27.
+    Such a term must not come back as a finite but wrong sum: the kernel flags the slab, the combine poisons the
+    panel's sums with NaN, and -- like the flat path and the reference -- the factors / RMSE go non-finite.
+    Every entry that is non-finite on the flat path must be non-finite in scatter mode too."""
+    d = mfx.dataset.synth_ratings(400, 300, 8000, seed=9, test_frac=0.02).copy()
+    q = 1234
+    for bad in (np.float32(np.inf), np.float32(np.nan), np.float32(3e38)):
+        e = d.copy()
+        e.csr_val[q] = bad
+        row = int(np.searchsorted(e.csr_row_ptr, q, side="right") - 1)
+        col = int(e.csr_col_idx[q])
+        lo, hi = int(e.csc_col_ptr[col]), int(e.csc_col_ptr[col + 1])
+        e.csc_val[lo + int(np.where(e.csc_row_idx[lo:hi] == row)[0][0])] = bad
+        out = {}
+        for name, kw in (("flat", {}), ("scatter", {"kernel_variant": 2, "panel_rows": 64})):
+            s = mfx.CcdSolver(e, mfx.test_data_of(e), _p(mfx, 3, 1, 1, **kw))
+            s.set_factors(mfx.initial_col(3, e.rows))
+            rep = s.iterate(1)
+            out[name] = s.get_factors() + (rep[0].rmse,)
+            s.close()
+        for a, b in zip(out["flat"][:2], out["scatter"][:2]):
+            assert not np.all(np.isfinite(b)), bad  # (3e38: a finite rating whose terms exceed the fixed-point range)
+            if not np.isfinite(bad):
+                assert not np.all(np.isfinite(a))
+                assert np.all(~np.isfinite(b[~np.isfinite(a)])), bad
+
+
 def test_bad_arguments_are_errors(mfx):
     d = mfx.dataset.synth_ratings(50, 40, 500, seed=1)
     with pytest.raises(mfx.MfxError, match="maxinneriter"):

@@ -351,6 +351,64 @@ def test_config5_shard_vs_oracle():
     assert np.abs(csc - csc_ref).max() < 1e-3 and np.abs(csr - csr_ref).max() < 1e-3
 
 
+def test_config5_sharded_solve_at_the_real_message_size():
+    """configs[4]'s per-inner-iteration exchange at its real size: n = 1 000 000 item columns, so every rank's column
+    partials are a 2 x 1 M fp32 = 8 MB all-reduce buffer -- scatter layout on both sides (hyper-sparse), slabs ->
+    k_scatter_combine -> dense (g, h) -> all-reduce over the shards -> finalize from the reduced buffer with the GLOBAL
+    |Omega_c| -> local u-pass.  Two nnz-balanced user-row shards (threads of this process on one GPU, loopback
+    communicator: RCCL refuses two ranks on one device) of a 500 000 x 1 000 000 matrix with 5e7 ratings, against the
+    UNSHARDED oracle on the whole matrix, k = 4, two outer iterations."""
+    import threading
+    import torch
+    import mfx
+    from mfx import synth_torch
+    from oracle import oracle as orc
+    rows, cols, nnz, k, t, nshards = 500_000, 1_000_000, 50_000_000, 4, 2, 2
+    dev = synth_torch.synth_ratings_device(rows, cols, nnz, seed=55, device="cuda:0", sigma_rows=0.5, sigma_cols=1.0)
+    d = synth_torch.to_rating_data(dev)
+    del dev
+    torch.cuda.empty_cache()
+    W0 = mfx.initial_col(k, rows)
+    bounds = mfx.partition_rows(d, nshards)
+    gcnt = np.ascontiguousarray(np.diff(d.csc_col_ptr.astype(np.int64)).astype(np.uint32))
+    out, errs = [None] * nshards, []
+
+    def run(r):
+        try:
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            shard = mfx.extract_shard(d, lo, hi)
+            comm = mfx.Comm(None, r, nshards, 0, local_group=9050)
+            p = mfx.parameter()
+            p.k, p.lambda_, p.maxiter, p.profile = k, 0.05, t, 1
+            s = mfx.CcdSolver(shard, mfx.test_data_of(shard), p, comm=comm, global_col_nnz=gcnt, global_test_nnz=d.nnz_test)
+            info = s.layout_info()
+            s.set_factors(np.ascontiguousarray(W0[:, lo:hi]))
+            status = comm.agree(0)
+            assert status == 0
+            rep = s.iterate(t)
+            out[r] = (s.get_factors(), [x.rmse for x in rep], info, s.kernel_times())
+            s.close(); comm.close()
+        except Exception as e:
+            errs.append(e)
+            raise
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(nshards)]
+    [x.start() for x in th]
+    [x.join(timeout=600) for x in th]
+    assert not errs and all(o is not None for o in out), errs
+    for (_, _), _, info, times in out:
+        assert info["csc"]["kind"] == "scatter" and info["csr"]["kind"] == "scatter", info
+        assert times["rccl_allreduce"][1] >= k * t and "ccd_scatter_combine" in times and "ccd_scatter_v_pass" in times
+    Wr, Hr, rmse_ref, *_ = orc.ccdr1(d, W0, k, 0.05, t, 1, orc.max_threads())
+    W = np.concatenate([o[0][0] for o in out], axis=1)
+    scale = float(max(np.abs(Wr).max(), np.abs(Hr).max()))
+    assert np.abs(W - Wr).max() < 2e-3 * scale
+    for (Wl, Hl), rm, _, _ in out:
+        assert np.abs(Hl - Hr).max() < 2e-3 * scale
+        assert np.all(np.abs(np.array(rm) - rmse_ref) < 1e-4), (rm, rmse_ref)
+    assert np.array_equal(out[0][0][1].view(np.uint32), out[1][0][1].view(np.uint32))  # the H replicas agree bit for bit
+
+
 def test_fullsize_fused_finalize_is_bit_identical(big, monkeypatch):
     """Opt-in path (MFX_FUSE_FINALIZE=1; off by default, it measured slower).  Netflix shape, k = 64, two outer iterations (256 fused passes, ~3 000 workgroups each, on all eight XCDs): the
     in-pass finalize reads other workgroups' partial sums of the same launch; one stale read would change bits."""
