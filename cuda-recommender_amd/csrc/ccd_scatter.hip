@@ -31,7 +31,19 @@
 // 54 KB slice, zeroing 109 KB of LDS, writing a 107 KB slab (read again by the combine) and -- alone on its CU --
 // leaving the CU idle through its own prologue and epilogue.  Now ~256 + npanels slabs instead of 2180 (the slabs
 // of a panel are still consecutive: ranges and panels are both ascending), and a wave's tile pipeline runs on
-// across chunk boundaries.
+// across chunk boundaries.  Measured on the shard (profiles/r03_sweep_shard_persistent.txt): column-sum pass 454 ->
+// 365 us (0.53 of the roofline), row-sum pass 476 -> 462 us (0.42), combine 39 -> 12 us, outer iteration at k = 128
+// 132 -> 111 ms; and the span length no longer matters (2 ... 14 tiles: 111-115 ms; round 2's 444-713 us scatter over
+// 8 ... 32 tiles was the per-chunk prologue / epilogue, whose weight changed with the chunk size).
+// What bounds a pass now is the CU's read path from L2: rocprofv3 counts 42 (column sums) / 54 (row sums) 128-byte
+// TCP -> TCC read requests per 256-entry tile (profiles/r03_pmc_scatter*.txt), and both passes run at one request
+// per ~10.7 clocks per CU -- the same ~12 B/clk/CU the flat pass streams at.  14 of those lines are the streams
+// (7 B per entry); the other 28 / 40 are the streamed operand: at 0.68 entries per (panel, id) pair every line of the
+// operand is fetched once per panel and half of its entries are used (8-byte pairs: 2 KB useful of 3.6 KB; 12-byte
+// triples in the row-sum pass: 3 KB of 5.1 KB).  Tried on the persistent kernel and dropped (no change beyond
+// noise): de-phasing the 16 waves of a workgroup with a per-wave start delay (the units are not used in bursts), and
+// an XCD-major range order in which each XCD owns a contiguous eighth of the panels (L2 hits on the operand do not
+// relieve the CU's request path -- same finding as in round 2).
 //
 // Measured on the shard shape (k = 128): 0.51 ms (column sums, 8-byte streamed operand) / 0.66 ms (row sums,
 // 16-byte operand) per pass against 0.85 / 0.93 ms for cache panels; 244 -> 160 ms per outer iteration.  What
@@ -102,7 +114,6 @@ struct ScatterArgs {
     const uint32_t* chunk_lo; // [workgroups + 1] chunk range of every persistent workgroup
     const uint32_t* slab0;    // [workgroups] first slab a workgroup writes (one per panel it visits, ascending)
     uint32_t* slab_bad;       // [slabs] != 0: some term of the slab was NaN / Inf / beyond the fixed-point range
-    uint32_t stagger;         // wave w idles w * stagger * 64 clocks before its first tile (de-phases the 16 waves of a workgroup)
     int add;
 };
 
@@ -279,7 +290,6 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
             }
             return r;
         };
-        for (uint32_t i = 0; i < wave * a.stagger; ++i) __builtin_amdgcn_s_sleep(1);
         Tile A = stream(next_tile()), B;
         Gath ga, gb;
         for (uint32_t q = 0; q < Q; q += 2) {
@@ -363,8 +373,6 @@ int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_sr
     a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;
     a.chunk_lo = s.scat_chunk_lo; a.slab0 = s.scat_slab0; a.slab_bad = s.scat_slab_bad;
     a.add = add;
-    a.stagger = 0;
-    if (const char* e = std::getenv("MFX_SCATTER_STAGGER")) a.stagger = (uint32_t) std::max(0, std::atoi(e));
     MFX_REQUIRE(s.scat_nwg > 0 && s.scat_chunk_lo && s.scat_slab0 && s.slab_lo && s.scat_slab_bad, "launch_scatter: the layout carries no workgroup ranges");
     MFX_REQUIRE(s.segid || (s.seg_delta && s.tile_base), "launch_scatter: the layout carries no segment ids");
     const bool ids32 = s.seg_delta == nullptr;

@@ -700,12 +700,10 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
         o.scatter = true; o.lds = true; o.spans_per_wg = 16;
         o.scatter_ids32 = p->kernel_variant == 3;
         o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : kScatterPanel, std::max<uint32_t>(G, 1u));
-        // spans of 14 tiles when the matrix is large: a workgroup then flushes its 107 KB slab once per 57 k entries.
-        // Measured on the config-5 shard (tools/sweep_shard.sh, profiles/r02_sweep_shard.txt): 8 ... 32 tiles give
-        // 444-713 / 470-656 us per pass with no monotone trend (padding of every panel to whole chunks, slab traffic
-        // and address aliasing between the 16 spans of a workgroup pull in different directions); 14 is the best for
-        // both copies together.
-        o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : (nnz_ >= (32u << 20) ? 14u : 0u);
+        // spans of 4 tiles when the matrix is large: with persistent workgroups (ccd_scatter.hip) the span length only
+        // sets the granularity of their chunk ranges and the padding at every panel's end -- 2 ... 14 tiles measure
+        // within 3 % of each other on the config-5 shard (profiles/r03_sweep_shard_persistent.txt), 28 is 12 % slower.
+        o.tiles_per_span = p->tiles_per_span > 0 ? (uint32_t) p->tiles_per_span : (nnz_ >= (32u << 20) ? 4u : 0u);
         return o;
     };
     scatter_ = scatter;
