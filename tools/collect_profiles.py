@@ -1,61 +1,88 @@
 #!/usr/bin/env python3
-"""Copies the judged summaries of tools/prof_r01_final.sh from gpurun_out/final into profiles/
-and derives profiles/traffic.json (HBM bytes per launch of the fused passes, read by bench.py)."""
-import csv, glob, json, os, subprocess, sys
+"""Copies the judged summaries of tools/prof_r03_final.sh from gpurun_out/final/<tag>/ into profiles/<round>_* and
+rebuilds profiles/traffic.json: HBM bytes per launch of the dominant kernels from the FETCH_SIZE / WRITE_SIZE passes,
+each entry tied to the shape it was measured at, the date and the hash of the kernel sources (bench.py only quotes an
+entry whose hash matches the sources it runs from).        usage: collect_profiles.py r03"""
+import csv, datetime, glob, hashlib, json, os, subprocess, sys
 csv.field_size_limit(1 << 30)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst, tag = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles"), sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 os.makedirs(dst, exist_ok=True)
-rows = []
-# gpurun merges into gpurun_out/ without deleting older runs: keep only the newest file per pass
-def newest(dirname, pattern):
-    fs = glob.glob(os.path.join(src, dirname, "**", pattern), recursive=True)
-    return [max(fs, key=os.path.getmtime)] if fs else []
-for f in newest("stats", "*kernel_stats.csv"):
-    rd = list(csv.reader(open(f)))
-    rows = [rd[0]] + [r for r in rd[1:] if "mfx" in r[0]]
-csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w")).writerows(rows)
-for f in newest("stats_als", "*kernel_stats.csv"):
-    rd = list(csv.reader(open(f)))
-    csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats_als.csv"), "w")).writerows([rd[0]] + [r for r in rd[1:] if "mfx" in r[0]])
-with open(os.path.join(dst, f"{tag}_pmc.txt"), "w") as out:
-    for d in ("fetch", "write", "l2", "sq"):
-        out.write(f"== rocprofv3 --pmc pass: {d}\n")
-        out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parse_pmc.py"), os.path.join(src, d), "mfx"],
-                                 capture_output=True, text=True).stdout)
-line = [l for l in open(os.path.join(src, "bench.log")) if l.startswith("{")][-1]
-open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
-als = [l for l in open(os.path.join(src, "bench_als.log")) if l.startswith("{")]
-if als:
-    open(os.path.join(dst, f"{tag}_bench_als.json"), "w").write(als[-1])
-for extra, name in (("bench_als128.log", "bench_als_k128"), ("bench_shard.log", "bench_shard")):
-    pth = os.path.join(src, extra)
-    if os.path.exists(pth):
-        ls = [l for l in open(pth) if l.startswith("{")]
-        if ls:
-            open(os.path.join(dst, f"{tag}_{name}.json"), "w").write(ls[-1])
-for f in newest("stats_shard", "*kernel_stats.csv"):
-    rd = list(csv.reader(open(f)))
-    csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats_shard.csv"), "w")).writerows([rd[0]] + [r for r in rd[1:] if "mfx" in r[0]])
-bench = json.loads(line)
-Z = int(bench["config"]["nnz_global"])
-def mean(dirname, kern, ctr):
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in ("ccd_kernels.hip", "ccd_scatter.hip", "flat_layout.hpp"):
+        h.update(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest(path, pattern):  # gpurun merges into gpurun_out/ without deleting older runs: keep the newest file per pass
+    fs = glob.glob(os.path.join(path, "**", pattern), recursive=True)
+    return max(fs, key=os.path.getmtime) if fs else None
+
+
+def mean_counter(path, kern, ctr):
+    f = newest(path, "*counter_collection.csv")
+    if not f:
+        return None
     s = n = 0
-    for f in newest(dirname, "*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr:
-                s += float(r["Counter_Value"]); n += 1
+    for r in csv.DictReader(open(f)):
+        if kern in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+            s += float(r["Counter_Value"]); n += 1
     return s / n if n else None
+
+
+# bench kernel name -> substring of the device kernel's name
+KERNELS = {"ccd_fused_csc_pass": "k_flat<2", "ccd_fused_csr_pass": "k_flat<3", "ccd_scatter_v_pass": "k_scatter<0", "ccd_scatter_u_pass": "k_scatter<1"}
 traffic = {}
-for name, kern in (("ccd_fused_csc_pass", "k_flat<2"), ("ccd_fused_csr_pass", "k_flat<3")):
-    fetch_kb, write_kb = mean("fetch", kern, "FETCH_SIZE"), mean("write", kern, "WRITE_SIZE")
-    if fetch_kb is None or write_kb is None:
+tpath = os.path.join(dst, "traffic.json")
+if os.path.exists(tpath):
+    try:
+        traffic = {k: v for k, v in json.load(open(tpath)).items() if "@" in k}  # keep other shapes' entries
+    except Exception:
+        traffic = {}
+for wl in sorted(os.listdir(src)) if os.path.isdir(src) else []:
+    d = os.path.join(src, wl)
+    if not os.path.isdir(d):
         continue
-    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
-    # half of the bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B stores.
-    traffic[name] = {"nnz": Z, "fetch_size_kib_raw": fetch_kb, "write_size_kib_raw": write_kb,
-                     "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
-                     "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE half-count correction"}
-json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-print(open(os.path.join(dst, f"{tag}_pmc.txt")).read())
-print(json.dumps(traffic, indent=1))
+    blog = os.path.join(d, "bench.log")
+    lines = [l for l in open(blog) if l.startswith("{")] if os.path.exists(blog) else []
+    if lines:
+        open(os.path.join(dst, f"{tag}_bench_{wl}.json"), "w").write(lines[-1])
+    f = newest(os.path.join(d, "stats"), "*kernel_stats.csv")
+    if f:
+        rd = list(csv.reader(open(f)))
+        csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats_{wl}.csv"), "w")).writerows([rd[0]] + [r for r in rd[1:] if "mfx" in r[0]])
+    pmc_dirs = sorted(p for p in glob.glob(os.path.join(d, "pmc_*")) if os.path.isdir(p))
+    if pmc_dirs:
+        with open(os.path.join(dst, f"{tag}_pmc_{wl}.txt"), "w") as out:
+            for p in pmc_dirs:
+                out.write(f"== rocprofv3 --pmc pass: {os.path.basename(p)[4:]}\n")
+                out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parse_pmc.py"), p, "mfx"], capture_output=True, text=True).stdout)
+    if not lines:
+        continue
+    bench = json.loads(lines[-1])
+    cfg = bench.get("config", {})
+    if "rows_per_gpu" not in cfg:
+        continue
+    # the PMC passes ran the same shape (possibly at a smaller k: traffic per launch does not depend on k)
+    Z = int(cfg["nnz_global"]) if bench.get("n_gpus", 1) == 1 else None
+    for name, kern in KERNELS.items():
+        fetch_kb, write_kb = mean_counter(os.path.join(d, "pmc_fetch_size"), kern, "FETCH_SIZE"), mean_counter(os.path.join(d, "pmc_write_size"), kern, "WRITE_SIZE")
+        if fetch_kb is None or write_kb is None or Z is None:
+            continue
+        # MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of the
+        # bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-byte stores.  For the scatter
+        # passes a third of the read requests are 8- / 12-byte gathers, for which the half-count is not established:
+        # the corrected figure is an UPPER bound there and the raw sum is kept beside it.
+        traffic[f"{name}@{Z}"] = {
+            "nnz": Z, "rows": int(cfg["rows_per_gpu"]), "cols": int(cfg["cols"]), "workload": wl,
+            "fetch_size_kib_raw": fetch_kb, "write_size_kib_raw": write_kb,
+            "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
+            "hbm_bytes_per_launch_uncorrected": int((fetch_kb + write_kb) * 1024),
+            "kernel_src_sha16": kernel_source_hash(), "collected": datetime.date.today().isoformat(),
+            "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE half-count correction"}
+json.dump(traffic, open(tpath, "w"), indent=1)
+print(json.dumps({k: (v["hbm_bytes_per_launch"], v["hbm_bytes_per_launch_uncorrected"]) for k, v in traffic.items()}, indent=1))
