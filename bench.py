@@ -72,6 +72,30 @@ def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
     kt = s.kernel_times()
     Z, k = host.nnz, a.k
     flops = 2.0 * (Z * k * (k + 1) + 2.0 * Z * k)  # both half-sweeps: symmetric Gramian + rhs
+    # Per half-sweep: the matrix-core roofline (Z k (k + 1) + 2 Z k flop of symmetric Gramian + rhs) AND the gather
+    # roofline -- SURVEY 8d: Z (8 + 4 k) bytes per half-sweep (index + rating + one k-float factor row per rating).  The
+    # factor rows come from L2 / Infinity Cache rather than HBM (the table is 4.5 / 123 MB), so the HBM peak is the
+    # generous yardstick; MI355X_MICROARCH.md puts the row-gather ceiling at 5.5-5.8 TB/s.
+    halves = {}
+    for name, (secs, n) in kt.items():
+        if n:
+            t_half = secs / n
+            halves[name] = {"ms": round(1e3 * t_half, 3),
+                            "mfma": {"achieved": round(0.5 * flops / t_half / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                                     "frac": round(0.5 * flops / t_half / 1e12 / 157.3, 4)},
+                            "gather": {"algorithmic_bytes": int(Z * (8 + 4 * k)), "achieved": round(Z * (8 + 4 * k) / t_half / 1e9, 1),
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(Z * (8 + 4 * k) / t_half / 1e9 / HBM_PEAK_GBS, 4)}}
+    traffic, traffic_source = None, "none: no PMC record for the ALS half-sweeps at this size in profiles/traffic.json"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        ent = tj.get(f"als_iteration_k{k}@{Z}")
+        if ent and ent.get("kernel_src_sha16") == als_source_hash():
+            traffic = ent.get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/traffic.json: rocprofv3 --pmc passes of {ent.get('collected', '?')} (both half-sweeps of one iteration)"
+        elif ent:
+            traffic_source = "stale: als_solver.hip changed since profiles/traffic.json was collected"
+    except Exception:
+        pass
     print(json.dumps({"metric": "ALS iteration time at k=%d" % k, "value": round(1e3 * el / a.steps, 3), "unit": "ms",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": False, "dtype": "f32",
                       "data": "synthetic", "config": {"workload": f"{host.rows}x{host.cols} nnz={Z} k={k}"},
@@ -79,7 +103,9 @@ def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
                       # whole iteration (Gramians + 2 x nseg Cholesky/solves) against the fp32 MFMA peak,
                       # counting only the symmetric half of each Gramian as useful work
                       "roofline": {"bound": "mfma", "achieved": round(flops / (el / a.steps) / 1e12, 2), "peak": 157.3,
-                                   "unit": "TFLOP/s", "frac": round(flops / (el / a.steps) / 1e12 / 157.3, 4), "traffic": None},
+                                   "unit": "TFLOP/s", "frac": round(flops / (el / a.steps) / 1e12 / 157.3, 4), "traffic": traffic,
+                                   "traffic_source": traffic_source},
+                      "half_sweeps": halves,
                       "kernels": {n: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1])} for n, v in kt.items()},
                       "rmse": [round(r.rmse, 6) for r in rep], "gen_seconds": round(gen_s, 2)}), flush=True)
     s.close()
@@ -93,6 +119,11 @@ def kernel_source_hash() -> str:
     for f in ("ccd_kernels.hip", "ccd_scatter.hip", "flat_layout.hpp"):
         h.update(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def als_source_hash() -> str:
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", "als_solver.hip"), "rb").read()).hexdigest()[:16]
 
 
 def free_port() -> int:
@@ -336,6 +367,7 @@ def main() -> None:
         "ccd_flat_resid": 12.0 * Z + flags + 4.0 * (m + n),
         "ccd_wave_sweep": 8.0 * Z + 4.0 * (m + n) + 8.0 * min(m, n),
         "ccd_wave_resid": 12.0 * Z + 4.0 * (m + n),
+        "ccd_ref_order_sweep": 8.0 * Z + 4.0 * (m + n) + 8.0 * min(m, n),  # parity mode (kernel_variant -1): latency-, not bandwidth-bound
         # scatter layout (hyper-sparse shards): the same contract as the fused passes they replace
         "ccd_scatter_v_pass": 12.0 * Z + flags + 8.0 * m + 8.0 * n + 8.0 * n,
         "ccd_scatter_u_pass": 12.0 * Z + flags + 16.0 * n + 8.0 * m + 8.0 * m,

@@ -60,7 +60,7 @@ for wl in sorted(os.listdir(src)) if os.path.isdir(src) else []:
         with open(os.path.join(dst, f"{tag}_pmc_{wl}.txt"), "w") as out:
             for p in pmc_dirs:
                 out.write(f"== rocprofv3 --pmc pass: {os.path.basename(p)[4:]}\n")
-                out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parse_pmc.py"), p, "mfx"], capture_output=True, text=True).stdout)
+                out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parse_pmc.py"), p, "re:k_flat|k_scatter|k_finalize|k_combine|k_als|k_sweep|k_resid"], capture_output=True, text=True).stdout)
     if not lines:
         continue
     bench = json.loads(lines[-1])
@@ -84,5 +84,33 @@ for wl in sorted(os.listdir(src)) if os.path.isdir(src) else []:
             "hbm_bytes_per_launch_uncorrected": int((fetch_kb + write_kb) * 1024),
             "kernel_src_sha16": kernel_source_hash(), "collected": datetime.date.today().isoformat(),
             "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE half-count correction"}
+# ALS: both half-sweeps of one iteration (k_als_gram* kernels; everything else in an iteration is negligible)
+for wl in ("als", "als128"):
+    d = os.path.join(src, wl)
+    blog = os.path.join(d, "bench.log")
+    if not os.path.exists(blog):
+        continue
+    lines = [l for l in open(blog) if l.startswith("{")]
+    if not lines:
+        continue
+    w = json.loads(lines[-1])["config"]["workload"]  # "<rows>x<cols> nnz=<Z> k=<k>"
+    Z, k = int(w.split("nnz=")[1].split()[0]), int(w.split("k=")[1])
+    per_kernel = {}
+    for ctr, sub in (("FETCH_SIZE", "pmc_fetch_size"), ("WRITE_SIZE", "pmc_write_size")):
+        f = newest(os.path.join(d, sub), "*counter_collection.csv")
+        if not f:
+            continue
+        for r in csv.DictReader(open(f)):
+            if "k_als_gram" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                per_kernel.setdefault(ctr, []).append(float(r["Counter_Value"]))
+    if len(per_kernel) == 2:
+        iters = max(1, len(per_kernel["FETCH_SIZE"]) // 2)  # two half-sweep launches per iteration
+        fetch_kb, write_kb = sum(per_kernel["FETCH_SIZE"]) / iters, sum(per_kernel["WRITE_SIZE"]) / iters
+        traffic[f"als_iteration_k{k}@{Z}"] = {
+            "nnz": Z, "k": k, "fetch_size_kib_raw": fetch_kb, "write_size_kib_raw": write_kb,
+            "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024), "hbm_bytes_per_launch_uncorrected": int((fetch_kb + write_kb) * 1024),
+            "kernel_src_sha16": hashlib.sha256(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", "als_solver.hip"), "rb").read()).hexdigest()[:16],
+            "collected": datetime.date.today().isoformat(),
+            "note": "sum over the two half-sweep kernels of one iteration; 2*FETCH_SIZE + WRITE_SIZE, gfx950 half-count correction (upper bound: most reads are 256-byte row gathers)"}
 json.dump(traffic, open(tpath, "w"), indent=1)
 print(json.dumps({k: (v["hbm_bytes_per_launch"], v["hbm_bytes_per_launch_uncorrected"]) for k, v in traffic.items()}, indent=1))

@@ -51,13 +51,18 @@ for case in range(a.cases):
     T = int(rng.choice([1, 1, 2, 3]))
     t = int(rng.choice([1, 2, 3]))
     p = mfx.parameter(); p.k, p.lambda_, p.maxiter, p.maxinneriter = k, lam, t, T
-    lay = rng.choice(["auto", "auto", "lds", "cache"] if a.big else ["auto", "plain", "lds", "cache", "hostbuilt", "wave", "written_flat"])
+    lay = rng.choice(["auto", "auto", "lds", "cache"] if a.big else ["auto", "plain", "lds", "cache", "hostbuilt", "wave", "written_flat", "scatter", "scatter", "reforder", "reforder"])
     if lay == "plain": p.panel_rows = -1
     elif lay == "lds": p.panel_rows = int(rng.choice([16, 100, 1000, 7000]))
     elif lay == "cache": p.panel_rows = -int(rng.choice([16, 100, 5000]))
     elif lay == "hostbuilt": p.layout_build = 1
     elif lay == "wave": p.schedule, p.kernel_variant = 0, 0
     elif lay == "written_flat": p.schedule, p.kernel_variant, p.panel_rows = 0, 1, int(rng.choice([0, 50, -50]))
+    elif lay == "scatter":  # persistent workgroups over random chunk ranges (r3)
+        p.kernel_variant, p.panel_rows = 2, int(rng.choice([0, 7, 64, 500, 6816]))
+        os.environ["MFX_SCATTER_WGS"] = str(int(rng.choice([1, 2, 3, 5, 16, 256, 100000])))
+    elif lay == "reforder":  # the reference's summation order: bit-identical to the oracle (r3)
+        p.schedule, p.kernel_variant = 0, -1
     p.tiles_per_span = int(rng.choice([0, 2, 4, 16]))
     p.wg_waves = int(rng.choice([0, 4, 8, 16]))
     p.graph = int(rng.choice([0, -1]))
@@ -91,6 +96,11 @@ for case in range(a.cases):
             print("worst H", ih, H[ih], Hr[ih], "col nnz", int(d.csc_col_ptr[ih[1] + 1] - d.csc_col_ptr[ih[1]]))
             print("count W entries off by > 1e-3*scale:", int((dW > 1e-3 * scale).sum()), " H:", int((dH > 1e-3 * scale).sum()), "layout", info)
         good = err < 1e-2 and rerr < 1e-4 and res < 5e-3 * max(1.0, float(np.abs(csc_ref).max()) if d.nnz else 1.0)
+        if lay == "reforder":  # not a tolerance: the same bits (NaN patterns included)
+            same = all(np.array_equal(x.view(np.uint32), y.view(np.uint32)) for x, y in ((W, Wr), (H, Hr), (csc, csc_ref), (csr, csr_ref)))
+            if not same:
+                fails.append(f"REFORDER {tag}: not bit-identical to the oracle (factor err {err:.2e}, residual err {res:.2e})")
+            good = True
         if not good and d.nnz:
             # Disagreement with the fp32 oracle: on poorly determined problems (tiny lambda, segments with a
             # handful of ratings, 10^4-term sequential fp32 sums in the reference) the ORACLE is the one that

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc counter_collection CSVs: mean counter value per kernel name.
-usage: parse_pmc.py <dir-or-csv> [name-filter]"""
-import csv, glob, os, sys
+usage: parse_pmc.py <dir-or-csv> [name-filter: substring, or a regular expression after "re:"]"""
+import csv, glob, os, re, sys
 from collections import defaultdict
 csv.field_size_limit(1 << 30)
 path = sys.argv[1]
@@ -10,7 +10,7 @@ files = [path] if path.endswith(".csv") else glob.glob(os.path.join(path, "**", 
 acc = defaultdict(lambda: [0.0, 0])
 for f in files:
     for r in csv.DictReader(open(f)):
-        if flt not in r["Kernel_Name"]:
+        if (not re.search(flt[3:], r["Kernel_Name"])) if flt.startswith("re:") else (flt not in r["Kernel_Name"]):
             continue
         name = r["Kernel_Name"].split("(mfx")[0].replace("void ", "").replace("mfx::(anonymous namespace)::", "")
         key = (name, r["Counter_Name"])
