@@ -982,7 +982,8 @@ int CcdSolver::resid(SegStreamStore& s, const float* gathered, const float* per_
         PROF(KernelProfiler::K_SCAT_RESID, launch_scatter(SM_RESID, s.view, gathered, per_seg, add, st_));
         return MFX_OK;
     }
-    if (p_.kernel_variant <= 0)
+    if (p_.kernel_variant == 0)  // (the reference-order mode, -1, takes the flat kernel over its plain layout: the update is
+                                 // elementwise -- bit-exact in every kernel -- and the flat one is twice as fast)
         PROF(KernelProfiler::K_RESID_WAVE, launch_resid_wave(s.view, gathered, per_seg, add, st_));
     else
         PROF(KernelProfiler::K_RESID, launch_flat(FM_RESID, s.view, gathered, per_seg, add, st_));

@@ -387,7 +387,7 @@ def test_config5_shard_k128_vs_reference_order():
     torch.cuda.empty_cache()
     (W, H, rm), (Wx, Hx, rx) = out["product"], out["reference_order"]
     assert np.all(np.abs(rm - rx) < 1e-4), (rm, rx)
-    assert rx[1] < rx[0] and rm[1] < rm[0]
+    # (no monotonicity claim: 128 ranks on ~100 ratings per user overfit the planted rank-8 model, the test RMSE rises)
     scale = float(max(np.abs(Wx).max(), np.abs(Hx).max()))
     assert np.abs(W - Wx).max() < 2e-3 * scale and np.abs(H - Hx).max() < 2e-3 * scale
     print("config5 shard k=128: |rmse_product - rmse_reference_order| =", np.abs(rm - rx))
