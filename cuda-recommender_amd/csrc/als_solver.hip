@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <type_traits>
 
@@ -74,7 +75,16 @@ struct AlsArgs {
     float* ws;
     uint32_t* spd_fail;
     float* gram_out;  // != nullptr: dump the k x k Gramian (no lambda) of item 0 and stop
+    unsigned long long* phases;  // != nullptr (MFX_ALS_PHASES=1): s_memtime clocks per phase, summed over the waves:
+                                 // [0] Gramian loop, [1] staging into LDS, [2] factorisation, [3] triangular solves, [4] systems
 };
+__device__ __forceinline__ void phase_mark(const AlsArgs& a, int slot, unsigned long long& t) {
+    if (a.phases && t) {  // (t == 0: a caller that does not take part, e.g. the reducers of split segments)
+        const unsigned long long now = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.phases + slot, now - t);
+        t = now;
+    }
+}
 
 template <int NT> struct Tiles { static constexpr int kCount = NT * (NT + 1) / 2; };
 
@@ -174,9 +184,50 @@ __device__ __forceinline__ void chol_panel_pass(float* __restrict__ L, int J, in
     }
 }
 
-template <int NT>
-__device__ void chol_blocked(float* __restrict__ L, bool& spd_ok) {
+// (r3) The diagonal pass RIGHT-LOOKING and entirely in registers.  In the left-looking form above step i reads row i of
+// the diagonal block from LDS -- a row whose entries the previous steps have only just written there: an LDS write ->
+// read round trip inside every one of the 32 dependent steps of a pass, with one wave per SIMD and nothing to hide it
+// behind.  Here every lane keeps its row of the block column in registers, and once column i is scaled its rank-one
+// update is applied to the columns still to come, a_c -= l_i * L[c][i], with L[c][i] taken from lane c by v_readlane:
+// 496 readlane + fma pairs per pass instead of 120 ds_read_b128 and 260 v_pk_fma, but the dependent chain of a step is
+// readlane(pivot) -> rsq -> scale -> readlane -> fma (~50 clocks) and the LDS only sees the 32 column stores.  Lanes
+// 32..63 (the block below the diagonal one) run the very same updates on their rows.
+#ifndef MFX_ALS_RL
+#define MFX_ALS_RL 1
+#endif
+__device__ __forceinline__ void chol_diag_pass_rl(float* __restrict__ L, int J, int blk_hi, bool& spd_ok) {
     const int lane = (int) (threadIdx.x & 63), r31 = lane & 31, h = lane >> 5;
+    const bool stores = h == 0 || blk_hi >= 0;                    // lanes 32..63 without a block of their own shadow the diagonal block
+    const int row = ((h && blk_hi >= 0) ? blk_hi : J) * 32 + r31;
+    float* blk = L + roff(row) + J * 32;
+    f32x2 a2[16];  // columns (2 q, 2 q + 1) of the lane's row: the rank-one updates run as v_pk_fma_f32 on aligned pairs
+#pragma unroll
+    for (int q = 0; q < 32; q += 4) {  // (diagonal block: reads past the diagonal stay inside the image, never used)
+        const f32x4 x = *reinterpret_cast<const f32x4*>(blk + q);
+        a2[q / 2] = x.lo;
+        a2[q / 2 + 1] = x.hi;
+    }
+    auto rl = [](float x, int src_lane) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+    };
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const float piv = rl(a2[i / 2][i & 1], i);  // lane i < 32 owns the diagonal entry, all earlier rank-one updates applied
+        spd_ok = spd_ok && piv > 0.f;
+        const float l = a2[i / 2][i & 1] * __builtin_amdgcn_rsqf(piv);  // lane i: pivot / sqrt(pivot) = the diagonal entry
+        if (stores && (h || lane >= i)) blk[i] = l;
+        const f32x2 nl = {-l, -l};
+        if ((i & 1) == 0) a2[i / 2][1] = __builtin_fmaf(-l, rl(l, i + 1), a2[i / 2][1]);  // the odd partner of an even column
+#pragma unroll
+        for (int c = (i | 1) + 1; c < 32; c += 2)  // (rows above the diagonal: slots they never store)
+            a2[c / 2] = fma2(nl, f32x2{rl(l, c), rl(l, c + 1)}, a2[c / 2]);
+    }
+}
+
+template <int NT>
+__device__ void chol_blocked(float* __restrict__ L, bool& spd_ok, const AlsArgs& a) {
+    const int lane = (int) (threadIdx.x & 63), r31 = lane & 31, h = lane >> 5;
+    unsigned long long tsub = a.phases ? __builtin_readcyclecounter() : 0ull;  // [5] MFMA updates, [6] diagonal passes, [7] passes below
 #pragma unroll 1
     for (int J = 0; J < NT; ++J) {
         if (J > 0) {
@@ -189,13 +240,19 @@ __device__ void chol_blocked(float* __restrict__ L, bool& spd_ok) {
                 const float* rowJ = L + roff(J * 32 + r31) + 4 * h;
 #pragma unroll 1
                 for (int K = 0; K < J; ++K) {
+                    // all eight operand reads of the K-block go out before its first MFMA: one LDS latency per block
+                    // instead of four (the wave is alone on its SIMD: nothing else hides them)
+                    f32x4 av[4], bv[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const f32x4 av = *reinterpret_cast<const f32x4*>(rowI + K * 32 + 8 * t);
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(rowJ + K * 32 + 8 * t);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+                        av[t] = *reinterpret_cast<const f32x4*>(rowI + K * 32 + 8 * t);
+                        bv[t] = *reinterpret_cast<const f32x4*>(rowJ + K * 32 + 8 * t);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][e], bv[t][e], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {  // accumulator register r of lane l: row (r&3) + 8 (r>>2) + 4 h, column r31
@@ -204,20 +261,103 @@ __device__ void chol_blocked(float* __restrict__ L, bool& spd_ok) {
                 }
             }
             __syncthreads();
+            phase_mark(a, 5, tsub);
         }
-        chol_panel_pass<true>(L, J, J, J + 1 < NT ? J + 1 : -1, spd_ok);
+        if constexpr (MFX_ALS_RL != 0) chol_diag_pass_rl(L, J, J + 1 < NT ? J + 1 : -1, spd_ok);
+        else chol_panel_pass<true>(L, J, J, J + 1 < NT ? J + 1 : -1, spd_ok);
         __syncthreads();
+        phase_mark(a, 6, tsub);
 #pragma unroll 1
         for (int I0 = J + 2; I0 < NT; I0 += 2) chol_panel_pass<false>(L, J, I0, I0 + 1 < NT ? I0 + 1 : -1, spd_ok);
         __syncthreads();
+        phase_mark(a, 7, tsub);
     }
+}
+
+// (r3) Triangular solves for 64 < k <= 128 in 32-column blocks, every operand of the 2 x KP dependent steps in
+// registers.  The row-by-row form below reads L[lane][i] (forward) / L[i][lane] (backward) from LDS inside each step:
+// with one or two waves per SIMD nothing hides that read, and MFX_ALS_PHASES measured 90 000 clocks per system for the
+// solves at k = 128 -- more than the Gramian (85 000) or the factorisation (81 000).  Here a block's operands are
+// loaded up front -- forward: 32 consecutive entries of the lane's own rows (b128 reads); backward: element `lane` of 32
+// consecutive rows (lane-contiguous, conflict-free) -- and a step is scale, v_readlane, masked fma on the UNSCALED
+// unknowns (lane i carries z_i * L[i][i] until the end, as in the k <= 64 path).  Lane l owns rows l and l + 64; rows
+// k .. KP-1 are identity rows with a zero right-hand side, so no step needs a bound on k.
+template <int NT>
+__device__ __forceinline__ void solve_blocked(const float* __restrict__ L, const float* __restrict__ bv, const AlsArgs& a, uint32_t seg, int k) {
+    constexpr int KP = 32 * NT;
+    const int lane = (int) (threadIdx.x & 63);
+    const bool has1 = lane + 64 < KP;                 // (KP = 96: lanes 32..63 own no second row)
+    const int r1 = has1 ? lane + 64 : KP - 1;         // ... they shadow the last row and never store
+    float z0 = lane < k ? bv[lane] : 0.f;
+    float z1 = (has1 && lane + 64 < k) ? bv[lane + 64] : 0.f;
+    const float rp0 = rcp_nr(L[roff(lane) + lane]);
+    const float rp1 = rcp_nr(L[roff(r1) + r1]);
+    float lanef = (float) lane;
+    asm volatile("" : "+v"(lanef));  // (opaque: keeps the masks float compares, see factor_solve k <= 64)
+    auto rl = [](float x, int src_lane) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+    };
+    // ---- forward: L z = b
+#pragma unroll
+    for (int B = 0; B < NT; ++B) {
+        float a0[32], a1[32];
+#pragma unroll
+        for (int q = 0; q < 32; q += 4) {  // entries past a row's diagonal: inside the image, masked below
+            const f32x4 x = *reinterpret_cast<const f32x4*>(L + roff(lane) + 32 * B + q);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(L + roff(r1) + 32 * B + q);
+            a0[q] = x[0]; a0[q + 1] = x[1]; a0[q + 2] = x[2]; a0[q + 3] = x[3];
+            a1[q] = y[0]; a1[q + 1] = y[1]; a1[q + 2] = y[2]; a1[q + 3] = y[3];
+        }
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {
+            const int i = 32 * B + t;
+            if (i < 64) {
+                const float zi = rl(z0 * rp0, i);
+                z0 = lanef > (float) i ? __builtin_fmaf(-a0[t], zi, z0) : z0;
+                z1 = __builtin_fmaf(-a1[t], zi, z1);                      // rows 64 .. are all below row i
+            } else {
+                const float zi = rl(z1 * rp1, i - 64);
+                z1 = lanef > (float) (i - 64) ? __builtin_fmaf(-a1[t], zi, z1) : z1;
+            }
+        }
+    }
+    z0 *= rp0;
+    z1 *= rp1;
+    // ---- backward: L^T y = z
+#pragma unroll
+    for (int B = NT - 1; B >= 0; --B) {
+        float a0[32], a1[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) {  // element `lane` (and lane + 64) of rows 32 B + t: contiguous over the lanes
+            const float* row = L + roff(32 * B + t);
+            a0[t] = row[lane];
+            a1[t] = row[r1];
+        }
+#pragma unroll
+        for (int t = 31; t >= 0; --t) {
+            const int i = 32 * B + t;
+            if (i >= 64) {
+                const float yi = rl(z1 * rp1, i - 64);
+                z1 = lanef < (float) (i - 64) ? __builtin_fmaf(-a1[t], yi, z1) : z1;
+                z0 = __builtin_fmaf(-a0[t], yi, z0);                      // rows 0 .. 63 are all above row i
+            } else {
+                const float yi = rl(z0 * rp0, i);
+                z0 = lanef < (float) i ? __builtin_fmaf(-a0[t], yi, z0) : z0;
+            }
+        }
+    }
+    z0 *= rp0;
+    z1 *= rp1;
+    float* y = a.Y + (size_t) seg * k;
+    if (lane < k) y[lane] = z0;
+    if (has1 && lane + 64 < k) y[lane + 64] = z1;
 }
 
 // LDS image -> + lambda, Cholesky, two triangular solves, Y[seg] <- solution.
 // FULL: k == KP known at compile time (k = 64: no per-column `i < k` branches, no `lane < k` masks; user half at the
 // Netflix shape 8.24 -> 7.89 ms)
 template <int NT, bool FULL = false>
-__device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
+__device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg, unsigned long long tmark = 0) {
     constexpr int KP = 32 * NT;
     const uint32_t lane = threadIdx.x & 63;
     const int k = FULL ? KP : (int) a.k;
@@ -241,10 +381,12 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     // reference's single accumulator would be a 64-deep dependent chain per row).  k <= 64 and the blocked form use
     // fused multiply-adds and one 1/sqrt(pivot) scale per column; the legacy k > 64 row-by-row form keeps the
     // unfused arithmetic of round 1.
+    phase_mark(a, 1, tmark);  // staging (+ lambda, barriers)
     if constexpr (NT >= 3 && kBlockedCholesky) {  // (measured at k = 64: 16.9 ms per iteration blocked vs 15.9 in registers)
         bool spd_ok = true;
-        chol_blocked<NT>(L, spd_ok);
+        chol_blocked<NT>(L, spd_ok, a);
         if (lane == 0 && !spd_ok) atomicAdd(a.spd_fail, 1u);
+        phase_mark(a, 2, tmark);
     } else if constexpr (NT <= 2) {
         // k <= 64: lane j keeps its own row j in registers (static indices after full unrolling), so
         // only row i -- the same for every lane -- is read from LDS, as broadcast ds_read_b128 of
@@ -295,6 +437,7 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
             }
         }
         __syncthreads();
+        phase_mark(a, 2, tmark);
         // Triangular solves on the UNSCALED unknowns: lane i carries z_i * L[i][i] until the very end, so a step is
         // scale (one multiply for all lanes), broadcast (v_readlane), update (one masked fma) -- no per-step select of
         // the finished component.  The forward pass takes L[lane][i] from the lane's registers, the backward pass reads
@@ -330,6 +473,7 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
         // (the k > 64 form counts pivots)
         const bool broken = (int) lane < k && !(__builtin_fabsf(z) <= 3.0e38f);
         if (__ballot(broken) != 0 && lane == 0) atomicAdd(a.spd_fail, 1u);
+        phase_mark(a, 3, tmark);
         return;
     } else {
         // k > 64: rows do not fit the register file next to the accumulators; row i is a broadcast
@@ -363,6 +507,12 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
             __syncthreads();
         }
     }
+    if constexpr (NT >= 3 && kBlockedCholesky) {
+        __syncthreads();
+        solve_blocked<NT>(L, bv, a, seg, k);
+        phase_mark(a, 3, tmark);
+        return;
+    }
     // Triangular solves (column oriented; lane r owns row r, two rows per lane for k > 64).  The
     // pivots' reciprocals are taken once, in parallel, so that each of the 2k sequential steps is a
     // broadcast (v_readlane, uniform index), one multiply and one fused update.
@@ -392,6 +542,7 @@ __device__ void factor_solve(float* lds, const AlsArgs& a, uint32_t seg) {
     float* y = a.Y + (size_t) seg * k;
     if ((int) lane < k) y[lane] = z0;
     if (NT > 2 && (int) lane + 64 < k) y[lane + 64] = z1;
+    phase_mark(a, 3, tmark);
 }
 
 
@@ -414,6 +565,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(als_waves(NT
     }
     f32x16 acc[Tiles<NT>::kCount];
     float bacc[NT];
+    unsigned long long tmark = a.phases ? __builtin_readcyclecounter() : 0ull;
 #pragma unroll
     for (int t = 0; t < Tiles<NT>::kCount; ++t)
 #pragma unroll
@@ -565,8 +717,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(als_waves(NT
         for (int I = 0; I < NT; ++I) w[Tiles<NT>::kCount * 1024 + I * 64 + lane] = bacc[I];
         return;
     }
+    phase_mark(a, 0, tmark);
+    if (a.phases && lane == 0) atomicAdd(a.phases + 4, 1ull);
     stage_tiles32<NT>(acc, bacc, lds);
-    factor_solve<NT>(lds, a, it.seg);
+    factor_solve<NT>(lds, a, it.seg, tmark);
 }
 
 template <int NT>
@@ -776,6 +930,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         return;
     }
     Gram16Regs<D> r;
+    unsigned long long tmark = a.phases ? __builtin_readcyclecounter() : 0ull;
 #pragma unroll
     for (int t = 0; t < kTiles16; ++t) r.acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     r.bacc[0] = r.bacc[1] = f32x2{0.f, 0.f};
@@ -803,10 +958,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         for (int e = 0; e < kSets; ++e) w[kTiles16 * 256 + e * 64 + lane] = r.bacc[e >> 1][e & 1];
         return;
     }
+    phase_mark(a, 0, tmark);
+    if (a.phases && lane == 0) atomicAdd(a.phases + 4, 1ull);
     float bacc[kSets] = {r.bacc[0].x, r.bacc[0].y, r.bacc[1].x, r.bacc[1].y};
     if constexpr (FULL) stage_tiles16_perm(r.acc, bacc, lds);
     else stage_tiles16(r.acc, bacc, lds);
-    factor_solve<2, FULL>(lds, a, it.seg);
+    factor_solve<2, FULL>(lds, a, it.seg, tmark);
 }
 
 __global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
@@ -961,9 +1118,13 @@ int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, uint32_t G, const uint32_t* pt
     return MFX_OK;
 }
 
+// MFX_ALS_PHASES=1 (diagnostic): per-phase clocks of the half-sweep kernels, printed by AlsSolver::iterate
+static unsigned long long* g_phase_buf = nullptr;
+
 int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y, uint32_t k, float lambda, float* ws,
                     uint32_t* spd_fail, hipStream_t st) {
     AlsArgs a{};
+    a.phases = g_phase_buf;
     a.items = h.items.get(); a.reduces = h.reduces.get(); a.idx = h.idx.get(); a.val = h.val.get();
     a.X = X; a.x_rows = x_rows; a.sentinel = (uint32_t) h.nnz; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
     return launch_half(a, h.nitems, h.nreduces, h.nnz, st);
@@ -981,6 +1142,7 @@ int AlsSolver::create(AlsSolver** out, const mfx_csx* R, const mfx_coo* T, const
 
 AlsSolver::~AlsSolver() {
     (void) hipSetDevice(device_);
+    if (phases_.size() && g_phase_buf == phases_.get()) g_phase_buf = nullptr;
     for (hipEvent_t& e : ev_)
         if (e) (void) hipEventDestroy(e);
     if (st_) {
@@ -1046,6 +1208,7 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     MFX_TRY(H_.alloc_zero(((size_t) n_ + 1) * k_, st_));
     MFX_TRY(ws_.alloc(std::max<size_t>(1, als_ws_floats(std::max(rows_.nslots, cols_.nslots), k_))));
     MFX_TRY(spd_fail_.alloc_zero(1, st_));
+    if (std::getenv("MFX_ALS_PHASES")) { MFX_TRY(phases_.alloc_zero(8, st_)); g_phase_buf = phases_.get(); }
     nnz_test_ = T ? T->nnz : 0;
     if (!comm_) global_test_nnz_ = nnz_test_;
     if (nnz_test_ > 0) {
@@ -1079,6 +1242,17 @@ int AlsSolver::meet_shards() {
     return MFX_OK;
 }
 
+int AlsSolver::print_phases(const char* what) {
+    unsigned long long h[8] = {};
+    MFX_HIP(hipStreamSynchronize(st_));
+    MFX_HIP(hipMemcpy(h, phases_.get(), sizeof(h), hipMemcpyDeviceToHost));
+    MFX_HIP(hipMemset(phases_.get(), 0, sizeof(h)));
+    const double n = h[4] ? (double) h[4] : 1.0;
+    fprintf(stderr, "[mfx als phases] %-22s systems %llu; s_memtime clocks per system: gramian %.0f, staging %.0f, factorisation %.0f (k > 64: MFMA updates %.0f, "
+            "diagonal passes %.0f, passes below %.0f), solves %.0f\n", what, h[4], h[0] / n, h[1] / n, h[2] / n, h[5] / n, h[6] / n, h[7] / n, h[3] / n);
+    return MFX_OK;
+}
+
 int AlsSolver::set_factors(const float* W, const float* H, mfx_memspace space) {
     // W's initial content is irrelevant (overwritten before its first read, src/ALS.cpp:98-158)
     MFX_REQUIRE(H, "mfx_als_set_factors: H is required");
@@ -1105,6 +1279,7 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
                                     spd_fail_.get(), st_));
         if (comm_) MFX_TRY(exchange(W_.get(), row_bounds_));
         MFX_HIP(hipEventRecord(ev_[1], st_));
+        if (phases_.size()) MFX_TRY(print_phases("user half (W over H)"));
         if (p_.schedule == 0)
             MFX_TRY(als_half_exact_launch(cols_, W_.get(), H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, spd_fail_.get(), st_));
         else
@@ -1112,6 +1287,7 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
                                     spd_fail_.get(), st_));
         if (comm_) MFX_TRY(exchange(H_.get(), col_bounds_));
         MFX_HIP(hipEventRecord(ev_[2], st_));
+        if (phases_.size()) MFX_TRY(print_phases("item half (H over W)"));
         double rmse = 0.0, sum = 0.0;
         if (with_rmse && global_test_nnz_ > 0) {
             if (nnz_test_ > 0)

@@ -62,6 +62,8 @@ private:
     AlsHalf rows_, cols_;
     DevBuf<float> W_, H_, ws_;
     DevBuf<uint32_t> spd_fail_;
+    DevBuf<unsigned long long> phases_;  // MFX_ALS_PHASES=1: per-phase clocks of the half-sweep kernels (diagnostic)
+    int print_phases(const char* what);
     int64_t nnz_test_ = 0;
     DevBuf<uint32_t> t_row_, t_col_;
     DevBuf<float> t_val_;
