@@ -78,10 +78,11 @@ struct AlsArgs {
     unsigned long long* phases;  // != nullptr (MFX_ALS_PHASES=1): s_memtime clocks per phase, summed over the waves:
                                  // [0] Gramian loop, [1] staging into LDS, [2] factorisation, [3] triangular solves, [4] systems
 };
+constexpr uint32_t kPhaseCopies = 1024;
 __device__ __forceinline__ void phase_mark(const AlsArgs& a, int slot, unsigned long long& t) {
     if (a.phases && t) {  // (t == 0: a caller that does not take part, e.g. the reducers of split segments)
         const unsigned long long now = __builtin_readcyclecounter();
-        if ((threadIdx.x & 63) == 0) atomicAdd(a.phases + slot, now - t);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.phases + (blockIdx.x % kPhaseCopies) * 8 + slot, now - t);  // (spread: 480 k waves on one line serialise)
         t = now;
     }
 }
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(als_waves(NT
         return;
     }
     phase_mark(a, 0, tmark);
-    if (a.phases && lane == 0) atomicAdd(a.phases + 4, 1ull);
+    if (a.phases && lane == 0) atomicAdd(a.phases + (blockIdx.x % kPhaseCopies) * 8 + 4, 1ull);
     stage_tiles32<NT>(acc, bacc, lds);
     factor_solve<NT>(lds, a, it.seg, tmark);
 }
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         return;
     }
     phase_mark(a, 0, tmark);
-    if (a.phases && lane == 0) atomicAdd(a.phases + 4, 1ull);
+    if (a.phases && lane == 0) atomicAdd(a.phases + (blockIdx.x % kPhaseCopies) * 8 + 4, 1ull);
     float bacc[kSets] = {r.bacc[0].x, r.bacc[0].y, r.bacc[1].x, r.bacc[1].y};
     if constexpr (FULL) stage_tiles16_perm(r.acc, bacc, lds);
     else stage_tiles16(r.acc, bacc, lds);
@@ -1208,7 +1209,7 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     MFX_TRY(H_.alloc_zero(((size_t) n_ + 1) * k_, st_));
     MFX_TRY(ws_.alloc(std::max<size_t>(1, als_ws_floats(std::max(rows_.nslots, cols_.nslots), k_))));
     MFX_TRY(spd_fail_.alloc_zero(1, st_));
-    if (std::getenv("MFX_ALS_PHASES")) { MFX_TRY(phases_.alloc_zero(8, st_)); g_phase_buf = phases_.get(); }
+    if (std::getenv("MFX_ALS_PHASES")) { MFX_TRY(phases_.alloc_zero((size_t) kPhaseCopies * 8, st_)); g_phase_buf = phases_.get(); }
     nnz_test_ = T ? T->nnz : 0;
     if (!comm_) global_test_nnz_ = nnz_test_;
     if (nnz_test_ > 0) {
@@ -1244,9 +1245,12 @@ int AlsSolver::meet_shards() {
 
 int AlsSolver::print_phases(const char* what) {
     unsigned long long h[8] = {};
+    std::vector<unsigned long long> all((size_t) kPhaseCopies * 8);
     MFX_HIP(hipStreamSynchronize(st_));
-    MFX_HIP(hipMemcpy(h, phases_.get(), sizeof(h), hipMemcpyDeviceToHost));
-    MFX_HIP(hipMemset(phases_.get(), 0, sizeof(h)));
+    MFX_HIP(hipMemcpy(all.data(), phases_.get(), sizeof(unsigned long long) * all.size(), hipMemcpyDeviceToHost));
+    MFX_HIP(hipMemset(phases_.get(), 0, sizeof(unsigned long long) * all.size()));
+    for (size_t c = 0; c < kPhaseCopies; ++c)
+        for (int q = 0; q < 8; ++q) h[q] += all[c * 8 + q];
     const double n = h[4] ? (double) h[4] : 1.0;
     fprintf(stderr, "[mfx als phases] %-22s systems %llu; s_memtime clocks per system: gramian %.0f, staging %.0f, factorisation %.0f (k > 64: MFMA updates %.0f, "
             "diagonal passes %.0f, passes below %.0f), solves %.0f\n", what, h[4], h[0] / n, h[1] / n, h[2] / n, h[5] / n, h[6] / n, h[7] / n, h[3] / n);

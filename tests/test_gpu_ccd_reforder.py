@@ -111,6 +111,60 @@ def test_ccdpp_reference_order_ml1m_shape_vs_oracle_bit_exact(mfx, orc, T):
     assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-12)
 
 
+@pytest.mark.parametrize("rows,cols,nnz", [(1, 1, 1), (1, 40, 17), (50, 1, 23), (3, 2, 5), (7, 5, 0)])
+def test_reference_order_degenerate_shapes_bit_exact(mfx, orc, rows, cols, nnz):
+    """One row, one column, a handful of ratings, no ratings at all: still the oracle's bits (empty segments -> exactly 0)."""
+    rng = np.random.default_rng(rows * 100 + cols)
+    if nnz:
+        cells = rng.choice(rows * cols, nnz, replace=False)
+        d = mfx.dataset.from_coo(rows, cols, cells // cols, cells % cols, rng.uniform(1, 5, nnz).astype(np.float32),
+                                 [0], [0], np.array([3.0], np.float32))
+    else:
+        d = mfx.dataset.from_coo(rows, cols, [], [], np.zeros(0, np.float32), [1], [2], np.array([3.0], np.float32))
+    k, t = 3, 3
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, 0.05, t, 2, 2)
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, 0.05, t, 2))
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    W, H = s.get_factors()
+    csc, csr = s.get_residual(d.nnz)
+    s.close()
+    assert np.array_equal(bits(W), bits(Wr)) and np.array_equal(bits(H), bits(Hr))
+    assert np.array_equal(bits(csc), bits(csc_ref)) and np.array_equal(bits(csr), bits(csr_ref))
+    assert np.all(np.abs(np.array([r.rmse for r in rep]) - rmse_ref) < 1e-12)
+
+
+def test_reference_order_follows_the_stored_order_of_unsorted_segments(mfx, orc):
+    """The reference adds a column's terms in the order the file holds them (its loader does not sort): with the
+    entries of every row / column shuffled the sums change in the low bits -- and the parity mode must follow the
+    shuffled order, not some canonical one: bit-identical to the oracle on the SAME arrays, and different from the
+    solve on the sorted arrays."""
+    d0 = mfx.dataset.synth_ratings(700, 500, 30000, seed=77, skew=0.7, test_frac=0.02)
+    d = d0.copy()
+    rng = np.random.default_rng(5)
+    for ptr, idx, val in ((d.csr_row_ptr, d.csr_col_idx, d.csr_val), (d.csc_col_ptr, d.csc_row_idx, d.csc_val)):
+        for sgm in range(ptr.shape[0] - 1):
+            lo, hi = int(ptr[sgm]), int(ptr[sgm + 1])
+            if hi - lo > 1:
+                o = rng.permutation(hi - lo)
+                idx[lo:hi] = idx[lo:hi][o]
+                val[lo:hi] = val[lo:hi][o]
+    k, t = 5, 3
+    W0 = mfx.initial_col(k, d.rows)
+    out = []
+    for data in (d, d0):
+        Wr, Hr, *_ = orc.ccdr1(data, W0, k, 0.05, t, 1, 2)
+        s = mfx.CcdSolver(data, mfx.test_data_of(data), _params(mfx, k, 0.05, t, 1))
+        s.set_factors(W0.copy())
+        s.iterate(t)
+        W, H = s.get_factors()
+        s.close()
+        assert np.array_equal(bits(W), bits(Wr)) and np.array_equal(bits(H), bits(Hr))
+        out.append(W)
+    assert not np.array_equal(bits(out[0]), bits(out[1]))  # the order is visible in the bits
+
+
 def test_reference_order_mode_argument_checks(mfx):
     d = mfx.dataset.synth_ratings(300, 200, 5000, seed=1, test_frac=0.02)
     p = _params(mfx, 4, 0.05, 1, 1)
