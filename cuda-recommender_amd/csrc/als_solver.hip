@@ -1119,13 +1119,10 @@ int AlsHalf::build(uint32_t nseg_, uint64_t nnz_, uint32_t G, const uint32_t* pt
     return MFX_OK;
 }
 
-// MFX_ALS_PHASES=1 (diagnostic): per-phase clocks of the half-sweep kernels, printed by AlsSolver::iterate
-static unsigned long long* g_phase_buf = nullptr;
-
 int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y, uint32_t k, float lambda, float* ws,
-                    uint32_t* spd_fail, hipStream_t st) {
+                    uint32_t* spd_fail, hipStream_t st, unsigned long long* phases) {
     AlsArgs a{};
-    a.phases = g_phase_buf;
+    a.phases = phases;  // MFX_ALS_PHASES=1 (diagnostic): per-phase clocks of the half-sweep kernels, printed by AlsSolver::iterate
     a.items = h.items.get(); a.reduces = h.reduces.get(); a.idx = h.idx.get(); a.val = h.val.get();
     a.X = X; a.x_rows = x_rows; a.sentinel = (uint32_t) h.nnz; a.Y = Y; a.k = k; a.lambda = lambda; a.ws = ws; a.spd_fail = spd_fail; a.gram_out = nullptr;
     return launch_half(a, h.nitems, h.nreduces, h.nnz, st);
@@ -1143,7 +1140,6 @@ int AlsSolver::create(AlsSolver** out, const mfx_csx* R, const mfx_coo* T, const
 
 AlsSolver::~AlsSolver() {
     (void) hipSetDevice(device_);
-    if (phases_.size() && g_phase_buf == phases_.get()) g_phase_buf = nullptr;
     for (hipEvent_t& e : ev_)
         if (e) (void) hipEventDestroy(e);
     if (st_) {
@@ -1209,7 +1205,7 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     MFX_TRY(H_.alloc_zero(((size_t) n_ + 1) * k_, st_));
     MFX_TRY(ws_.alloc(std::max<size_t>(1, als_ws_floats(std::max(rows_.nslots, cols_.nslots), k_))));
     MFX_TRY(spd_fail_.alloc_zero(1, st_));
-    if (std::getenv("MFX_ALS_PHASES")) { MFX_TRY(phases_.alloc_zero((size_t) kPhaseCopies * 8, st_)); g_phase_buf = phases_.get(); }
+    if (std::getenv("MFX_ALS_PHASES")) { MFX_TRY(phases_.alloc_zero((size_t) kPhaseCopies * 8, st_)); }
     nnz_test_ = T ? T->nnz : 0;
     if (!comm_) global_test_nnz_ = nnz_test_;
     if (nnz_test_ > 0) {
@@ -1280,7 +1276,7 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
             MFX_TRY(als_half_exact_launch(rows_, H_.get(), W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, spd_fail_.get(), st_));
         else
             MFX_TRY(als_half_launch(rows_, H_.get(), n_, W_.get() + (size_t) row_lo_ * k_, k_, p_.lambda, ws_.get(),
-                                    spd_fail_.get(), st_));
+                                    spd_fail_.get(), st_, phases_.get()));
         if (comm_) MFX_TRY(exchange(W_.get(), row_bounds_));
         MFX_HIP(hipEventRecord(ev_[1], st_));
         if (phases_.size()) MFX_TRY(print_phases("user half (W over H)"));
@@ -1288,7 +1284,7 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
             MFX_TRY(als_half_exact_launch(cols_, W_.get(), H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, spd_fail_.get(), st_));
         else
             MFX_TRY(als_half_launch(cols_, W_.get(), m_, H_.get() + (size_t) col_lo_ * k_, k_, p_.lambda, ws_.get(),
-                                    spd_fail_.get(), st_));
+                                    spd_fail_.get(), st_, phases_.get()));
         if (comm_) MFX_TRY(exchange(H_.get(), col_bounds_));
         MFX_HIP(hipEventRecord(ev_[2], st_));
         if (phases_.size()) MFX_TRY(print_phases("item half (H over W)"));

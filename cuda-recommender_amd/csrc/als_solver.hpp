@@ -79,7 +79,7 @@ private:
 // Launches one half-sweep: Y[seg] = argmin over segment `seg` given factor rows X[x_rows + 1][k],
 // whose last row must be all zeros.
 int als_half_launch(const AlsHalf& h, const float* X, uint32_t x_rows, float* Y, uint32_t k, float lambda, float* ws,
-                    uint32_t* spd_fail, hipStream_t st);
+                    uint32_t* spd_fail, hipStream_t st, unsigned long long* phases = nullptr);
 // floats of workspace needed for `nslots` partial slots at rank k
 size_t als_ws_floats(uint32_t nslots, uint32_t k);
 
