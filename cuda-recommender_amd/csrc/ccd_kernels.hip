@@ -8,7 +8,6 @@
 #include "ccd_kernels.hpp"
 
 #include <algorithm>
-#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -171,7 +170,6 @@ struct FlatArgs {
     uint32_t* arrived;          // [groups] zero between launches: the completing workgroup resets its word
     const uint32_t* orphans;    // [norphans] groups nobody contributes to (all segments empty): slot 0 finalizes them
     uint32_t norphans, ngroups, panel_lanes;
-    uint32_t persist_wgs;       // != 0: LDS-panel pass as persistent workgroups over chunk ranges (the grid size)
     // what k_finalize takes
     uint32_t nseg, npanels;
     const uint32_t* ptr_v;
@@ -248,40 +246,23 @@ __device__ __forceinline__ float2 load_partial_sc1(const float2* p) {
     return make_float2(__builtin_bit_cast(float, (uint32_t) bits), __builtin_bit_cast(float, (uint32_t) (bits >> 32)));
 }
 
-// (LDS-panel passes: 64 VGPRs = two 1024-thread workgroups per CU; stated, because the chunk loop of the persistent form
-// otherwise tempts the allocator to 78 / 88 and one workgroup per CU)
 template <int MODE, bool LDS, int BLOCK, bool PSCHK, bool FUSE = false>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS && BLOCK == 1024 && !FUSE ? 8 : 1, 8))) void k_flat(FlatArgs a) {
+__global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     static_assert(!FUSE || (LDS && ModeTraits<MODE>::kDot), "fused finalize: LDS-panel passes that produce sums");
     using TR = ModeTraits<MODE>;
     // FUSE: dispatch slot -> chunk through wg_order (ascending first segment, so that the chunks of one segment
     // group run at about the same time and groups complete all along the pass, not at its end)
-    // (r3) PERSISTENT form for the LDS-panel passes (a.persist_wgs != 0: the grid is that many workgroups, two per CU):
-    // workgroup b walks the contiguous chunk range [nchunks b / G, nchunks (b + 1) / G) and re-stages the 56 KB slice
-    // only where the panel changes inside its range -- the per-segment window is per chunk as before.  Same spans,
-    // same arithmetic, same partial / carry slots: bit-identical results; what goes away is a workgroup launch, its
-    // slice load and the unbalanced last wave of workgroups per 32 k entries.
-    uint32_t chunk_lo = FUSE ? a.wg_order[blockIdx.x] : blockIdx.x, chunk_hi = chunk_lo + 1;
-    if constexpr (LDS && !FUSE) {
-        if (a.persist_wgs) {
-            const uint64_t nchunks = a.nspans / (BLOCK / 64);
-            chunk_lo = (uint32_t) (nchunks * blockIdx.x / a.persist_wgs);
-            chunk_hi = (uint32_t) (nchunks * (blockIdx.x + 1) / a.persist_wgs);
-        }
-    }
+    const uint32_t chunk = FUSE ? a.wg_order[blockIdx.x] : blockIdx.x;
     using G = typename TR::G;
     using P = typename TR::P;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     using S = typename TR::S;
     S* __restrict__ slice = reinterpret_cast<S*>(lds_raw);
     const uint32_t lane = threadIdx.x & 63;
+    const uint32_t span = __builtin_amdgcn_readfirstlane(chunk * (BLOCK / 64) + (threadIdx.x >> 6));
     const G* __restrict__ gather = static_cast<const G*>(a.gather);
     const P* __restrict__ perseg = static_cast<const P*>(a.perseg);
     const uint32_t span_words = a.tiles_per_span * (kTileElems / 32);
-    uint32_t staged_panel = 0xFFFFFFFFu;
-  for (uint32_t chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
-    if (chunk != chunk_lo) __syncthreads();  // every wave is done with the previous chunk's window (and slice)
-    const uint32_t span = __builtin_amdgcn_readfirstlane(chunk * (BLOCK / 64) + (threadIdx.x >> 6));
     const uint64_t start = (uint64_t) span * a.tiles_per_span * kTileElems;
     // panel-local indices are 16-bit: 2 B/nnz instead of 4 (10 B/nnz per fused pass instead of 12)
     using IdxVec = typename std::conditional<LDS, u16x4, u32x4>::type;
@@ -304,13 +285,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(LDS && BL
         fl_n = flw[0]; hp_n = hpw[0]; hp_nn = hpw[8];
         // stage this workgroup's panel slice; slot panel_rows is the zero entry padding points at
         const uint32_t panel = a.wg_panel[chunk];
-        if (panel != staged_panel) {
-            staged_panel = panel;
-            const uint32_t gbase = panel * a.panel_rows;
-            const uint32_t cnt = a.gather_len - gbase < a.panel_rows ? a.gather_len - gbase : a.panel_rows;
-            for (uint32_t i = threadIdx.x; i < cnt; i += BLOCK) slice[i] = to_slice<S, G>(gather[gbase + i]);
-            if (threadIdx.x == 0) slice[a.panel_rows] = S{};
-        }
+        const uint32_t gbase = panel * a.panel_rows;
+        const uint32_t cnt = a.gather_len - gbase < a.panel_rows ? a.gather_len - gbase : a.panel_rows;
+        for (uint32_t i = threadIdx.x; i < cnt; i += BLOCK) slice[i] = to_slice<S, G>(gather[gbase + i]);
+        if (threadIdx.x == 0) slice[a.panel_rows] = S{};
     }
     // The workgroup touches a contiguous window of ranks; stage their per-segment operands next to
     // the slice so that segmented tiles read LDS instead of chasing seg_of_rank -> perseg through L2.
@@ -493,7 +471,6 @@ __builtin_nontemporal_store(f32x4{vo[0], vo[1], vo[2], vo[3]}, val4 + tile * 64)
         }
     }
     if constexpr (FUSE) fused_finalize<BLOCK>(a, chunk, lds_raw);
-  }  // chunk loop
 }
 
 
@@ -958,32 +935,17 @@ int launch_flat_lds(const SegStreamDev& s, const FlatArgs& a, uint32_t grid, siz
     return launch_flat_t<MODE, true, BLOCK, false>(a, grid, lds_bytes, st);
 }
 
-// Persistent grid of the LDS-panel passes: resident workgroups per CU (64 KB of LDS each: two; BLOCK threads each against
-// 2048 per CU) x CUs.  MFX_FLAT_PERSIST=0 restores one workgroup per chunk (A/B), =N pins N workgroups per CU.
-static uint32_t flat_persist_wgs(uint32_t spans_per_wg) {
-    static const int per_cu_env = [] { const char* e = std::getenv("MFX_FLAT_PERSIST"); return e ? std::atoi(e) : -1; }();
-    if (per_cu_env == 0) return 0;
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
-    const uint32_t by_threads = 2048u / (64u * spans_per_wg), by_lds = 2u;
-    const uint32_t per_cu = per_cu_env > 0 ? (uint32_t) per_cu_env : std::min(by_threads, by_lds);
-    return per_cu * (uint32_t) cus;
-}
-
 template <int MODE>
 int launch_flat_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
     if (!s.lds_panels)
         return launch_flat_t<MODE, false, kBlock, false>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), 0, st);
     size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(typename ModeTraits<MODE>::S) + 15) / 16 * 16;
     if (ModeTraits<MODE>::kPerSeg) lds_bytes += (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
-    uint32_t grid = s.nspans / s.spans_per_wg;
-    FlatArgs ap = a;
-    const uint32_t pw = flat_persist_wgs(s.spans_per_wg);
-    if (pw && grid > pw) { ap.persist_wgs = pw; grid = pw; }
+    const uint32_t grid = s.nspans / s.spans_per_wg;
     switch (s.spans_per_wg) {
-        case 4: return launch_flat_lds<MODE, 256>(s, ap, grid, lds_bytes, st);
-        case 8: return launch_flat_lds<MODE, 512>(s, ap, grid, lds_bytes, st);
-        case 16: return launch_flat_lds<MODE, 1024>(s, ap, grid, lds_bytes, st);
+        case 4: return launch_flat_lds<MODE, 256>(s, a, grid, lds_bytes, st);
+        case 8: return launch_flat_lds<MODE, 512>(s, a, grid, lds_bytes, st);
+        case 16: return launch_flat_lds<MODE, 1024>(s, a, grid, lds_bytes, st);
         default: return fail(MFX_ERR_INVALID, "panel layout: spans_per_wg must be 4, 8 or 16 (got %u)", s.spans_per_wg);
     }
 }
