@@ -223,37 +223,45 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
     };
     bool bad = false;  // a term that the fixed-point accumulators cannot hold (NaN, Inf, |x| >= 2^27)
     auto compute = [&](const Tile& x, const Gath& gp) {
+        // three phases, so that the four slice reads go out together and the eight atomics follow without an LDS read
+        // between them (element by element every slice read also waited for the previous element's atomics: lgkmcnt(0))
         f32x4 o;
+        float gc[4], hc[4];
+        S sp[4];
+        if constexpr (TR::kSlice) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sp[e] = slice[x.l[e]];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t l = x.l[e];
-            float gc, hc;
             if constexpr (MODE == SM_V) {
-                const float2 sp = slice[l];
-                o[e] = add_rn(sub_rn(x.v[e], mul_rn(gp.g[e].x, sp.x)), mul_rn(gp.g[e].y, sp.y));
-                gc = gp.g[e].y * o[e];
-                hc = gp.g[e].y * gp.g[e].y;
+                o[e] = add_rn(sub_rn(x.v[e], mul_rn(gp.g[e].x, sp[e].x)), mul_rn(gp.g[e].y, sp[e].y));
+                gc[e] = gp.g[e].y * o[e];
+                hc[e] = gp.g[e].y * gp.g[e].y;
             } else if constexpr (MODE == SM_U) {
-                const float2 sp = slice[l];
-                o[e] = add_rn(sub_rn(x.v[e], mul_rn(gp.g[e].x, sp.x)), mul_rn(gp.g[e].y, sp.y));
-                gc = gp.g[e].z * o[e];
-                hc = gp.g[e].z * gp.g[e].z;
+                o[e] = add_rn(sub_rn(x.v[e], mul_rn(gp.g[e].x, sp[e].x)), mul_rn(gp.g[e].y, sp[e].y));
+                gc[e] = gp.g[e].z * o[e];
+                hc[e] = gp.g[e].z * gp.g[e].z;
             } else if constexpr (MODE == SM_SWEEP) {
                 o[e] = x.v[e];
-                gc = gp.g[e] * x.v[e];
-                hc = gp.g[e] * gp.g[e];
+                gc[e] = gp.g[e] * x.v[e];
+                hc[e] = gp.g[e] * gp.g[e];
             } else {
-                const float prod = mul_rn(slice[l], gp.g[e]);
+                const float prod = mul_rn(sp[e], gp.g[e]);
                 o[e] = a.add ? add_rn(x.v[e], prod) : sub_rn(x.v[e], prod);
-                gc = 0.f; hc = 0.f;
-            }
-            if constexpr (TR::kAcc) {
-                bad |= !(__builtin_fabsf(gc) < kFixedLimit) | !(hc < kFixedLimit);  // (NaN compares false)
-                atomicAdd(&acc[2 * l], to_fixed(gc));
-                atomicAdd(&acc[2 * l + 1], to_fixed(hc));
+                gc[e] = 0.f; hc[e] = 0.f;
             }
         }
         if constexpr (TR::kWrite) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(a.val + (uint64_t) x.tile * 256) + lane);
+        if constexpr (TR::kAcc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t l = x.l[e];
+                bad |= !(__builtin_fabsf(gc[e]) < kFixedLimit) | !(hc[e] < kFixedLimit);  // (NaN compares false)
+                atomicAdd(&acc[2 * l], to_fixed(gc[e]));
+                atomicAdd(&acc[2 * l + 1], to_fixed(hc[e]));
+            }
+        }
     };
 
     const uint32_t c_end = a.chunk_lo[blockIdx.x + 1];
@@ -290,19 +298,38 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
             }
             return r;
         };
-        Tile A = stream(next_tile()), B;
-        Gath ga, gb;
-        for (uint32_t q = 0; q < Q; q += 2) {
-            ga = gather(A);
-            B = stream(next_tile());
+        // (r4) Software pipeline: the streams run THREE tiles ahead of the tile being computed, its gathers ONE tile ahead.
+        // With the workgroups phase-aligned (whole panels each, see SegStreamStore::build_device) the streamed operand is
+        // served by L2, and what bounded the pass next was the memory in flight per CU: one workgroup of 16 waves with one
+        // tile of streams (1.8 KB read) outstanding each cannot cover the loaded HBM latency (29 KB per CU in flight ->
+        // 4.9 TB/s of streams with the gathers knocked out); and every tile exposed the L2 round trip of its own gathers
+        // (issued, then waited for).  Four statically named stream sets and two gather sets, rotated by unrolling.
+        Tile S0 = stream(next_tile()), S1 = stream(next_tile()), S2 = stream(next_tile()), S3;
+        Gath G0 = gather(S0), G1;
+        uint32_t q = 0;
+        for (; q + 4 <= Q; q += 4) {
+            G1 = gather(S1); S3 = stream(next_tile());
             __builtin_amdgcn_sched_barrier(0);
-            compute(A, ga);
+            compute(S0, G0);
             __builtin_amdgcn_sched_barrier(0);
-            gb = gather(B);
-            A = stream(next_tile());
+            G0 = gather(S2); S0 = stream(next_tile());
             __builtin_amdgcn_sched_barrier(0);
-            compute(B, gb);
+            compute(S1, G1);
             __builtin_amdgcn_sched_barrier(0);
+            G1 = gather(S3); S1 = stream(next_tile());
+            __builtin_amdgcn_sched_barrier(0);
+            compute(S2, G0);
+            __builtin_amdgcn_sched_barrier(0);
+            G0 = gather(S0); S2 = stream(next_tile());
+            __builtin_amdgcn_sched_barrier(0);
+            compute(S3, G1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q < Q) {  // Q is even: two tiles left, S0 (gathered) and S1
+            G1 = gather(S1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(S0, G0);
+            compute(S1, G1);
         }
         if constexpr (TR::kAcc) {
             if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) bad_any = 1;

@@ -700,6 +700,28 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
         o.scatter = true; o.lds = true; o.spans_per_wg = 16;
         o.scatter_ids32 = p->kernel_variant == 3;
         o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : kScatterPanel, std::max<uint32_t>(G, 1u));
+        // (r4) PHASE ALIGNMENT.  The persistent workgroups own equal, contiguous ranges of the panel-major stream, and inside
+        // a panel the streamed operand is read in ascending order: workgroup w starts at phase frac(w * P / nwg) of "its"
+        // panel and all of them advance at the same rate.  With P = 147 or 184 panels for 256 workgroups those phases are
+        // 256 different ones -- at any moment the chip reads 256 places spread over the whole 10-12 MB operand, nothing of
+        // it stays in a 4 MB L2 until the next panel comes by, and every operand line is an L2 MISS (round 3's counters:
+        // TCC_MISS = all reads).  With P a multiple of nwg / 8 the phase of workgroup w depends on w mod 8 only -- and so
+        // does its XCD (workgroup b is dispatched to XCD b % 8): every XCD's workgroups walk the operand IN STEP, one window
+        // of it is live per L2, and the operand lines of all but the first panel are L2 hits (TCC_MISS 23.1 M -> 12.6 M per
+        // u-pass, the streams alone; profiles/r04_exp_align.txt).  Equal nnz per range is kept, so a skewed matrix only
+        // blurs the windows.  MFX_SCATTER_PANEL_MULT overrides the multiple (0: round 3's panel count).
+        if (p->panel_rows == 0) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) {
+                uint32_t mult = (uint32_t) cus / 8;
+                if (const char* e = std::getenv("MFX_SCATTER_PANEL_MULT")) mult = (uint32_t) std::max(0, std::atoi(e));
+                const uint32_t p0 = (G + kScatterPanel - 1) / kScatterPanel;
+                if (mult > 0 && p0 >= mult) {
+                    const uint32_t P = (p0 + mult - 1) / mult * mult;
+                    o.panel_rows = (G + P - 1) / P;
+                }
+            }
+        }
         // spans of 4 tiles when the matrix is large: with persistent workgroups (ccd_scatter.hip) the span length only
         // sets the granularity of their chunk ranges and the padding at every panel's end -- 2 ... 14 tiles measure
         // within 3 % of each other on the config-5 shard (profiles/r03_sweep_shard_persistent.txt), 28 is 12 % slower.
