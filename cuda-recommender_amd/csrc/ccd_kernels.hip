@@ -574,6 +574,7 @@ struct FinKernelArgs {
     GatherPartsArgs parts;
     const uint32_t* seg_cnt;
     const float* gh_dense;
+    uint32_t seg_base, gh_len;  // dense source: segments [seg_base, seg_base + gh_len), g then h in gh_dense (a panel group)
     const uint32_t* cnt_override;
     float lambda;
     float* out_vec;
@@ -592,8 +593,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     // not queue up behind the rank -> part -> (barrier) chain.
     constexpr int SEGS = kBlock / PL;
     const bool flat = !a.gh_dense;
-    const uint32_t c0 = flat ? blockIdx.x * SEGS + threadIdx.x % SEGS : blockIdx.x * kBlock + threadIdx.x;
-    const bool owner = c0 < a.parts.nseg && (!flat || threadIdx.x / SEGS == 0);
+    const uint32_t dl = blockIdx.x * kBlock + threadIdx.x;  // dense source: index inside the group's block
+    const uint32_t c0 = flat ? blockIdx.x * SEGS + threadIdx.x % SEGS : a.seg_base + dl;
+    const bool owner = flat ? (c0 < a.parts.nseg && threadIdx.x / SEGS == 0) : dl < a.gh_len;
     uint32_t cnt = 0;
     float2 old = make_float2(0.f, 0.f);
     float next = 0.f;
@@ -605,9 +607,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     float g, h;
     if (a.gh_dense) {  // PL == 1 by construction
         c = c0;
-        if (c >= a.parts.nseg) return;
-        g = a.gh_dense[c];
-        h = a.gh_dense[a.parts.nseg + c];
+        if (dl >= a.gh_len) return;
+        g = a.gh_dense[dl];
+        h = a.gh_dense[a.gh_len + dl];
     } else if (!block_segment_sums<PL>(a.parts, c, g, h)) {
         return;
     }
@@ -1070,9 +1072,13 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
     if (s.nseg == 0) return MFX_OK;
     FinKernelArgs a;
     a.parts = parts_of(s); a.seg_cnt = s.seg_cnt; a.gh_dense = f.gh_dense; a.cnt_override = f.cnt_override;
+    a.seg_base = f.gh_len ? f.seg_base : 0u; a.gh_len = f.gh_len ? f.gh_len : s.nseg;
+    MFX_REQUIRE(!f.gh_len || (f.gh_dense && (uint64_t) f.seg_base + f.gh_len <= s.nseg), "launch_finalize: bad segment range %u + %u of %u", f.seg_base, f.gh_len, s.nseg);
     a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4; a.pack4_as3 = f.pack4_as3; a.nmf = f.nmf; a.fundec_seg = f.fundec_seg;
     const int pl = f.gh_dense ? 1 : panel_lanes(s);
-    const dim3 grid((s.nseg + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
+    const uint32_t nfin = f.gh_dense ? a.gh_len : s.nseg;
+    if (nfin == 0) return MFX_OK;
+    const dim3 grid((nfin + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
     if (pl == 16) hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, st, a);
     else if (pl == 4) hipLaunchKernelGGL(k_finalize<4>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(k_finalize<1>, grid, block, 0, st, a);

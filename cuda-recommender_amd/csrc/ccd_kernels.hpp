@@ -47,9 +47,18 @@ struct SegStreamDev {
     const uint8_t* seg_delta = nullptr;        // [padded nnz] step from the previous entry of the tile's sorted order
     const uint32_t* tile_base = nullptr;       // [padded nnz / 256] segment of a tile's first sorted entry
     unsigned long long* wgacc = nullptr;       // [slabs][2 * panel_rows] fixed-point (g, h) slabs
-    uint32_t scat_nwg = 0;                     // persistent workgroups of the scatter pass (one per CU, or fewer chunks)
-    const uint32_t* scat_chunk_lo = nullptr;   // [scat_nwg + 1] chunk range of every persistent workgroup
-    const uint32_t* scat_slab0 = nullptr;      // [scat_nwg] first slab of a workgroup (it writes one per panel it visits)
+    uint32_t scat_nwg = 0;                     // persistent workgroups of the scatter pass (one per CU, or fewer chunks): of the widest launch
+    const uint32_t* scat_chunk_lo = nullptr;   // [sum over groups (nwg + 1)] chunk range of every persistent workgroup, group after group
+    const uint32_t* scat_slab0 = nullptr;      // [sum over groups nwg] first slab of a workgroup (it writes one per panel it visits)
+    // (r4) PANEL GROUPS: the pass can be launched group by group (consecutive panels each), so that the sums of group j
+    // are final -- and can be combined, all-reduced and finalized on a second stream -- while group j + 1 is streamed.
+    // One group (the whole store) unless the solver overlaps a collective with the pass (sharded column side).
+    static constexpr uint32_t kMaxScatterGroups = 16;
+    uint32_t scat_ngroups = 1;
+    uint32_t scat_grp_nwg[kMaxScatterGroups] = {};       // workgroups of group j's launch
+    uint32_t scat_grp_tab[kMaxScatterGroups] = {};       // offset of its chunk ranges in scat_chunk_lo
+    uint32_t scat_grp_wg0[kMaxScatterGroups] = {};       // offset of its workgroups in scat_slab0
+    uint32_t scat_grp_lo[kMaxScatterGroups + 1] = {};    // first local index (of the gathered dimension) of group j; [ngroups] = gather_len
     const uint32_t* slab_lo = nullptr;         // [npanels + 1] first slab of every panel (a panel's slabs are consecutive)
     uint32_t* scat_slab_bad = nullptr;         // [slabs] a term of the slab was not representable in the fixed-point sums
     // fused finalize (LDS panels, 16-span workgroups): see fused_finalize in ccd_kernels.hip; nullptr = not available
@@ -87,9 +96,12 @@ enum ScatterMode : int {
     SM_SWEEP = 2,  // streamed float x: g += x*val ; h += x*x
     SM_RESID = 3,  // slice float y, streamed float x: val (+/-)= y*x
 };
-int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st);
-// slabs of a scatter pass -> dense gh[0..G) = g, gh[G..2G) = h over the local dimension (G = s.gather_len)
-int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st);
+// group: panel group to launch (SegStreamDev::scat_ngroups), -1 = all of them, one launch after the other
+int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st, int group = -1);
+// slabs of a scatter pass -> dense (g, h) over the local dimension, GROUP-MAJOR: group j with local indices [lo, hi)
+// owns gh[2 lo .. 2 hi): g of its indices first, then h -- one contiguous all-reduce buffer per group; with one group
+// that is gh[0..G) = g, gh[G..2G) = h (G = s.gather_len)
+int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st, int group = -1);
 
 // Wave-per-segment kernels (plain layout only: they walk the input-order arrays).
 int launch_sweep_wave(const SegStreamDev& s, const float* vec, float* g_dense, float* h_dense,
@@ -111,6 +123,9 @@ int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st);
 // dense, already all-reduced buffer gh_dense[2*nseg].
 struct FinalizeArgs {
     const float* gh_dense = nullptr;    // [2*nseg] or nullptr
+    // dense source restricted to the segments [seg_base, seg_base + gh_len) (a panel group of the scatter pass): gh_dense
+    // then points at that group's block -- gh_len sums g, then gh_len sums h; gh_len = 0 means all nseg segments
+    uint32_t seg_base = 0, gh_len = 0;
     const uint32_t* cnt_override = nullptr;  // global |Omega_c| (multi-GPU) or nullptr = local count
     float lambda = 0.f;
     float* out_vec = nullptr;           // W[t] / H[t] slice, [nseg]

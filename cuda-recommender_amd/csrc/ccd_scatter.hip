@@ -352,11 +352,12 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
 // term its fixed-point accumulators cannot hold (NaN, Inf, |x| >= 2^27: a diverging solve) poisons the panel's sums
 // with NaN -- the flat path and the reference propagate non-finite values the same way -- instead of delivering
 // finite but wrong numbers.
-__global__ __launch_bounds__(256) void k_scatter_combine(uint32_t G, uint32_t pr, const uint32_t* __restrict__ slab_lo,
+__global__ __launch_bounds__(256) void k_scatter_combine(uint32_t c_lo, uint32_t c_hi, uint32_t pr, const uint32_t* __restrict__ slab_lo,
                                                          const unsigned long long* __restrict__ wgacc,
                                                          const uint32_t* __restrict__ slab_bad, float* __restrict__ gh) {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= G) return;
+    // local indices [c_lo, c_hi) = one panel group; its block of gh starts at 2 c_lo: g of the group, then h
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, c = c_lo + i, len = c_hi - c_lo;
+    if (c >= c_hi) return;
     const uint32_t p = c / pr, l = c - p * pr;
     unsigned long long g = 0, h = 0;
     uint32_t bad = 0;
@@ -367,14 +368,15 @@ __global__ __launch_bounds__(256) void k_scatter_combine(uint32_t G, uint32_t pr
         bad |= slab_bad[w];
     }
     constexpr double inv = 1.0 / 68719476736.0;
-    gh[c] = bad ? __builtin_nanf("") : (float) ((double) (long long) g * inv);
-    gh[G + c] = bad ? __builtin_nanf("") : (float) ((double) (long long) h * inv);
+    float* out = gh + 2 * (size_t) c_lo;
+    out[i] = bad ? __builtin_nanf("") : (float) ((double) (long long) g * inv);
+    out[len + i] = bad ? __builtin_nanf("") : (float) ((double) (long long) h * inv);
 }
 
 template <int MODE, bool IDS32>
-int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, hipStream_t st) {
+int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, uint32_t nwg, hipStream_t st) {
     const size_t lds = scat_lds_bytes<MODE>(s.panel_rows);
-    MFX_REQUIRE(lds <= 160 * 1024, "scatter layout: %u local entries do not fit LDS", s.panel_rows);
+    MFX_REQUIRE(lds + 64 <= 160 * 1024, "scatter layout: %u local entries do not fit LDS", s.panel_rows);  // (+ the static bad_any word)
     if (lds > 48 * 1024) {  // a per-device attribute of the kernel: set once per (instantiation, device)
         static std::mutex m;
         static size_t set_bytes[64] = {};
@@ -386,36 +388,49 @@ int launch_scatter_t(const SegStreamDev& s, const ScatterArgs& a, hipStream_t st
             if (dev >= 0 && dev < 64) set_bytes[dev] = lds;
         }
     }
-    hipLaunchKernelGGL((k_scatter<MODE, IDS32>), dim3(s.scat_nwg), dim3(kScatBlock), lds, st, a);
+    hipLaunchKernelGGL((k_scatter<MODE, IDS32>), dim3(nwg), dim3(kScatBlock), lds, st, a);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
 
 }  // namespace
 
-int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st) {
+int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_src, const void* global_op, int add, hipStream_t st, int group) {
     MFX_REQUIRE(s.scatter && s.spans_per_wg == kScatBlock / 64 && s.tiles_per_span % 2 == 0, "launch_scatter: not a scatter layout");
-    ScatterArgs a;
-    a.lidx = s.idx16; a.segid = s.segid; a.seg_delta = s.seg_delta; a.tile_base = s.tile_base; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
-    a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;
-    a.chunk_lo = s.scat_chunk_lo; a.slab0 = s.scat_slab0; a.slab_bad = s.scat_slab_bad;
-    a.add = add;
     MFX_REQUIRE(s.scat_nwg > 0 && s.scat_chunk_lo && s.scat_slab0 && s.slab_lo && s.scat_slab_bad, "launch_scatter: the layout carries no workgroup ranges");
     MFX_REQUIRE(s.segid || (s.seg_delta && s.tile_base), "launch_scatter: the layout carries no segment ids");
+    MFX_REQUIRE(s.scat_ngroups >= 1 && s.scat_ngroups <= SegStreamDev::kMaxScatterGroups && group < (int) s.scat_ngroups, "launch_scatter: bad panel group %d of %u", group, s.scat_ngroups);
     const bool ids32 = s.seg_delta == nullptr;
-    switch (mode) {
-        case SM_V: return ids32 ? launch_scatter_t<SM_V, true>(s, a, st) : launch_scatter_t<SM_V, false>(s, a, st);
-        case SM_U: return ids32 ? launch_scatter_t<SM_U, true>(s, a, st) : launch_scatter_t<SM_U, false>(s, a, st);
-        case SM_SWEEP: return ids32 ? launch_scatter_t<SM_SWEEP, true>(s, a, st) : launch_scatter_t<SM_SWEEP, false>(s, a, st);
-        case SM_RESID: return ids32 ? launch_scatter_t<SM_RESID, true>(s, a, st) : launch_scatter_t<SM_RESID, false>(s, a, st);
-        default: return fail(MFX_ERR_INVALID, "launch_scatter: bad mode %d", (int) mode);
+    for (uint32_t g = group < 0 ? 0u : (uint32_t) group; g < (group < 0 ? s.scat_ngroups : (uint32_t) group + 1); ++g) {
+        const uint32_t nwg = s.scat_grp_nwg[g];
+        if (nwg == 0) continue;  // (a group without chunks: fewer panels than groups)
+        ScatterArgs a;
+        a.lidx = s.idx16; a.segid = s.segid; a.seg_delta = s.seg_delta; a.tile_base = s.tile_base; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
+        a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;
+        a.chunk_lo = s.scat_chunk_lo + s.scat_grp_tab[g]; a.slab0 = s.scat_slab0 + s.scat_grp_wg0[g]; a.slab_bad = s.scat_slab_bad;
+        a.add = add;
+        int rc;
+        switch (mode) {
+            case SM_V: rc = ids32 ? launch_scatter_t<SM_V, true>(s, a, nwg, st) : launch_scatter_t<SM_V, false>(s, a, nwg, st); break;
+            case SM_U: rc = ids32 ? launch_scatter_t<SM_U, true>(s, a, nwg, st) : launch_scatter_t<SM_U, false>(s, a, nwg, st); break;
+            case SM_SWEEP: rc = ids32 ? launch_scatter_t<SM_SWEEP, true>(s, a, nwg, st) : launch_scatter_t<SM_SWEEP, false>(s, a, nwg, st); break;
+            case SM_RESID: rc = ids32 ? launch_scatter_t<SM_RESID, true>(s, a, nwg, st) : launch_scatter_t<SM_RESID, false>(s, a, nwg, st); break;
+            default: return fail(MFX_ERR_INVALID, "launch_scatter: bad mode %d", (int) mode);
+        }
+        MFX_TRY(rc);
     }
+    return MFX_OK;
 }
 
-int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st) {
+int launch_scatter_combine(const SegStreamDev& s, float* gh, hipStream_t st, int group) {
     if (s.gather_len == 0) return MFX_OK;
-    hipLaunchKernelGGL(k_scatter_combine, dim3((s.gather_len + 255) / 256), dim3(256), 0, st, s.gather_len, s.panel_rows, s.slab_lo, s.wgacc, s.scat_slab_bad, gh);
-    MFX_HIP(hipGetLastError());
+    MFX_REQUIRE(s.scat_ngroups >= 1 && s.scat_ngroups <= SegStreamDev::kMaxScatterGroups && group < (int) s.scat_ngroups, "launch_scatter_combine: bad panel group %d of %u", group, s.scat_ngroups);
+    for (uint32_t g = group < 0 ? 0u : (uint32_t) group; g < (group < 0 ? s.scat_ngroups : (uint32_t) group + 1); ++g) {
+        const uint32_t lo = s.scat_grp_lo[g], hi = s.scat_grp_lo[g + 1];
+        if (hi <= lo) continue;
+        hipLaunchKernelGGL(k_scatter_combine, dim3((hi - lo + 255) / 256), dim3(256), 0, st, lo, hi, s.panel_rows, s.slab_lo, s.wgacc, s.scat_slab_bad, gh);
+        MFX_HIP(hipGetLastError());
+    }
     return MFX_OK;
 }
 

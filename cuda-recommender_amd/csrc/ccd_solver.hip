@@ -238,23 +238,36 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     uint32_t scat_nwg = 0;
     if (opt.scatter) {  // persistent workgroups: chunk ranges, the slabs they write, first slab of every panel; no partials / carries
         MFX_REQUIRE(opt.panel_rows && lds && spans_per_wg == 16, "scatter layout needs LDS panels and 16-span workgroups");
-        const uint32_t nchunks = nspans / spans_per_wg;
         int dev = 0, cus = 0;
         MFX_HIP(hipGetDevice(&dev));
         MFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        // one workgroup per CU (a workgroup takes the whole LDS); MFX_SCATTER_WGS overrides for experiments and tests
-        uint32_t want = cus > 0 ? (uint32_t) cus : 256u;
+        // one workgroup per CU (a workgroup takes the whole LDS) unless the solver asks for fewer (CUs left to a concurrent
+        // collective); MFX_SCATTER_WGS overrides for experiments and tests
+        uint32_t want = opt.scatter_wgs ? opt.scatter_wgs : (cus > 0 ? (uint32_t) cus : 256u);
         if (const char* e = std::getenv("MFX_SCATTER_WGS")) { const int v = std::atoi(e); if (v > 0) want = (uint32_t) v; }
-        scat_nwg = std::max(1u, std::min(want, nchunks));
-        std::vector<uint32_t> chunk_lo((size_t) scat_nwg + 1), slab0(scat_nwg), slab_lo((size_t) P + 1, 0u);
-        for (uint32_t w = 0; w <= scat_nwg; ++w) chunk_lo[w] = (uint32_t) ((uint64_t) nchunks * w / scat_nwg);
+        // panel groups (consecutive panels; one launch each, SegStreamDev::scat_ngroups): every launch spreads ITS chunks
+        // over the workgroups; the slabs are numbered across the groups, so a panel's slabs stay consecutive
+        const uint32_t ngroups = std::max(1u, std::min(std::min(opt.scatter_groups, P), (uint32_t) SegStreamDev::kMaxScatterGroups));
+        std::vector<uint32_t> chunk_lo, slab0, slab_lo((size_t) P + 1, 0u), slabs_of_panel(P, 0u);
         uint32_t nslabs = 0;
-        std::vector<uint32_t> slabs_of_panel(P, 0u);
-        for (uint32_t w = 0; w < scat_nwg; ++w) {
-            slab0[w] = nslabs;
-            for (uint32_t c = chunk_lo[w]; c < chunk_lo[w + 1]; ++c)
-                if (c == chunk_lo[w] || wg_panel[c] != wg_panel[c - 1]) { ++nslabs; ++slabs_of_panel[wg_panel[c]]; }
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            const uint32_t p_lo = (uint32_t) ((uint64_t) P * g / ngroups), p_hi = (uint32_t) ((uint64_t) P * (g + 1) / ngroups);
+            const uint32_t c_lo = (uint32_t) (base[p_lo] / chunk), c_hi = (uint32_t) (base[p_hi] / chunk);
+            const uint32_t nwg = c_hi > c_lo ? std::max(1u, std::min(want, c_hi - c_lo)) : 0u;
+            grp_nwg_[g] = nwg; grp_tab_[g] = (uint32_t) chunk_lo.size(); grp_wg0_[g] = (uint32_t) slab0.size();
+            grp_lo_[g] = std::min<uint64_t>((uint64_t) p_lo * opt.panel_rows, G);
+            scat_nwg = std::max(scat_nwg, nwg);
+            if (nwg == 0) continue;
+            const size_t t0 = chunk_lo.size();
+            for (uint32_t w = 0; w <= nwg; ++w) chunk_lo.push_back(c_lo + (uint32_t) ((uint64_t) (c_hi - c_lo) * w / nwg));
+            for (uint32_t w = 0; w < nwg; ++w) {
+                slab0.push_back(nslabs);
+                for (uint32_t c = chunk_lo[t0 + w]; c < chunk_lo[t0 + w + 1]; ++c)
+                    if (c == chunk_lo[t0 + w] || wg_panel[c] != wg_panel[c - 1]) { ++nslabs; ++slabs_of_panel[wg_panel[c]]; }
+            }
         }
+        grp_lo_[ngroups] = G;
+        ngroups_ = ngroups;
         // ranges and panels both ascend, so the slabs of a panel are consecutive in the numbering above
         for (uint32_t p = 0; p < P; ++p) slab_lo[p + 1] = slab_lo[p] + slabs_of_panel[p];
         MFX_REQUIRE(slab_lo[P] == nslabs, "scatter layout: slab bookkeeping is inconsistent (%u vs %u)", slab_lo[P], nslabs);
@@ -289,6 +302,11 @@ int SegStreamStore::build_device(uint32_t nseg, uint64_t nnz, uint32_t G, const 
     view.carry = carry_.get();
     view.scatter = opt.scatter; view.segid = segid_.get(); view.seg_delta = seg_delta_.get(); view.tile_base = tile_base_.get(); view.wgacc = wgacc_.get(); view.slab_lo = slab_lo_.get();
     view.scat_nwg = scat_nwg; view.scat_chunk_lo = scat_chunk_lo_.get(); view.scat_slab0 = scat_slab0_.get(); view.scat_slab_bad = scat_slab_bad_.get();
+    if (opt.scatter) {
+        view.scat_ngroups = ngroups_;
+        for (uint32_t g = 0; g < ngroups_; ++g) { view.scat_grp_nwg[g] = grp_nwg_[g]; view.scat_grp_tab[g] = grp_tab_[g]; view.scat_grp_wg0[g] = grp_wg0_[g]; }
+        for (uint32_t g = 0; g <= ngroups_; ++g) view.scat_grp_lo[g] = grp_lo_[g];
+    }
     *done = true;
     return MFX_OK;
 }
@@ -552,12 +570,13 @@ void KernelProfiler::reset_totals() {
     for (int i = 0; i < K_COUNT; ++i) { seconds[i] = 0; launches[i] = 0; }
 }
 
-#define PROF(id, call)                    \
-    do {                                  \
-        MFX_TRY(prof_.begin((id), st_));  \
-        MFX_TRY(call);                    \
-        MFX_TRY(prof_.end(st_));          \
+#define PROFS(id, stream, call)               \
+    do {                                      \
+        MFX_TRY(prof_.begin((id), (stream))); \
+        MFX_TRY(call);                        \
+        MFX_TRY(prof_.end((stream)));         \
     } while (0)
+#define PROF(id, call) PROFS(id, st_, call)
 
 // ------------------------------------------------------------------------------------------------
 int CcdSolver::create(CcdSolver** out, const mfx_csx* R, const mfx_coo* T, const mfx_params* p,
@@ -578,6 +597,13 @@ CcdSolver::~CcdSolver() {
         if (e) (void) hipEventDestroy(e);
     for (hipEvent_t& e : ev_rank_)
         if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t& e : ev_grp_)
+        if (e) (void) hipEventDestroy(e);
+    if (ev_join_) (void) hipEventDestroy(ev_join_);
+    if (st2_) {
+        (void) hipStreamSynchronize(st2_);
+        (void) hipStreamDestroy(st2_);
+    }
     if (st_) {
         (void) hipStreamSynchronize(st_);
         (void) hipStreamDestroy(st_);
@@ -616,12 +642,33 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         const FlatLayoutOptions a = choose_layout(*p, m_, nnz_, n_, kCsrSliceBytes, false), b = choose_layout(*p, n_, nnz_, m_, sizeof(float2), false);
         want_scatter = (a.panel_rows && !a.lds) || (b.panel_rows && !b.lds);
     }
+    // (r4) sharded solve in the scatter layout: the column pass runs panel group by panel group, and group j's sums are
+    // combined, all-reduced and finalized on a second stream while group j + 1 is streamed -- only the last group's
+    // exchange stays exposed.  RCCL's kernels need CUs of their own for that: one block of rcclGenericKernel holds 19.7 KB
+    // of LDS and ~280 registers per lane, and neither fits next to a scatter workgroup (150 KB of LDS, 4 x 112 registers per
+    // SIMD lane), so the column pass leaves `reserve` CUs free.  MFX_OVERLAP_GROUPS (1 = off) / MFX_COMM_RESERVE_CUS.
+    if (shard && shard->comm) {
+        const int nr = shard->comm->nranks;
+        int groups = nr > 1 ? 4 : 1, reserve = -1;
+        if (const char* e = std::getenv("MFX_OVERLAP_GROUPS")) groups = std::atoi(e);
+        if (const char* e = std::getenv("MFX_COMM_RESERVE_CUS")) reserve = std::atoi(e);
+        overlap_groups_ = (uint32_t) std::max(1, std::min(groups, (int) SegStreamDev::kMaxScatterGroups));
+        if (reserve < 0) reserve = (overlap_groups_ > 1 && nr > 1) ? 16 : 0;
+        comm_reserve_cus_ = overlap_groups_ > 1 ? (uint32_t) reserve : 0u;
+    }
     int rc = build_stores(R, p, space, want_scatter);
     if (rc != MFX_OK && want_scatter && p->kernel_variant != 2 && p->kernel_variant != 3) {  // e.g. unsorted indices: the ordinary layouts take anything
         csr_ = SegStreamStore(); csc_ = SegStreamStore();
         rc = build_stores(R, p, space, false);
     }
     MFX_TRY(rc);
+    if (!scatter_) overlap_groups_ = 1;
+    overlap_groups_ = std::min(overlap_groups_, csr_.view.scat_ngroups);
+    if (overlap_groups_ > 1) {
+        MFX_HIP(hipStreamCreateWithFlags(&st2_, hipStreamNonBlocking));
+        for (uint32_t g = 0; g < overlap_groups_; ++g) MFX_HIP(hipEventCreateWithFlags(&ev_grp_[g], hipEventDisableTiming));
+        MFX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
     if (ref_order_) {  // dispatch order of the reference-order sweeps: longest segment first (ccd_reforder.hip)
         for (int side = 0; side < 2; ++side) {
             const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
@@ -690,7 +737,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
 // the other).  Error text is thread-local, so it is carried across.
 int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace space, bool scatter) {
     const bool need_plain = p->schedule == 0 && p->kernel_variant <= 0;
-    auto options = [&](uint32_t nseg, uint32_t G, uint32_t elem_bytes) {
+    auto options = [&](uint32_t nseg, uint32_t G, uint32_t elem_bytes, bool is_csr) {
         if (!scatter) return choose_layout(*p, nseg, nnz_, G, elem_bytes, need_plain);
         // scatter: 24 B of LDS per local index (operand pair + two 64-bit accumulators) and the whole 160 KB of a CU
         // for one workgroup: 6816 + 1 padding slot = 163 608 B.  Fewer, larger panels = fewer re-reads of the
@@ -700,27 +747,37 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
         o.scatter = true; o.lds = true; o.spans_per_wg = 16;
         o.scatter_ids32 = p->kernel_variant == 3;
         o.panel_rows = std::min<uint32_t>(p->panel_rows > 0 ? (uint32_t) p->panel_rows : kScatterPanel, std::max<uint32_t>(G, 1u));
+        // the row-major store is the one the COLUMN pass streams: it alone is launched by panel groups / on fewer CUs
+        const uint32_t groups = is_csr ? overlap_groups_ : 1u;
+        o.scatter_groups = groups;
         // (r4) PHASE ALIGNMENT.  The persistent workgroups own equal, contiguous ranges of the panel-major stream, and inside
         // a panel the streamed operand is read in ascending order: workgroup w starts at phase frac(w * P / nwg) of "its"
-        // panel and all of them advance at the same rate.  With P = 147 or 184 panels for 256 workgroups those phases are
+        // panel and all of them advance at the same rate.  With P = 146.7 or 183.4 panels for 256 workgroups those phases are
         // 256 different ones -- at any moment the chip reads 256 places spread over the whole 10-12 MB operand, nothing of
         // it stays in a 4 MB L2 until the next panel comes by, and every operand line is an L2 MISS (round 3's counters:
-        // TCC_MISS = all reads).  With P a multiple of nwg / 8 the phase of workgroup w depends on w mod 8 only -- and so
-        // does its XCD (workgroup b is dispatched to XCD b % 8): every XCD's workgroups walk the operand IN STEP, one window
-        // of it is live per L2, and the operand lines of all but the first panel are L2 hits (TCC_MISS 23.1 M -> 12.6 M per
-        // u-pass, the streams alone; profiles/r04_exp_align.txt).  Equal nnz per range is kept, so a skewed matrix only
-        // blurs the windows.  MFX_SCATTER_PANEL_MULT overrides the multiple (0: round 3's panel count).
-        if (p->panel_rows == 0) {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 8) {
-                uint32_t mult = (uint32_t) cus / 8;
-                if (const char* e = std::getenv("MFX_SCATTER_PANEL_MULT")) mult = (uint32_t) std::max(0, std::atoi(e));
-                const uint32_t p0 = (G + kScatterPanel - 1) / kScatterPanel;
-                if (mult > 0 && p0 >= mult) {
-                    const uint32_t P = (p0 + mult - 1) / mult * mult;
-                    o.panel_rows = (G + P - 1) / P;
-                }
+        // TCC_MISS = all reads).  With EQUAL panels and P a multiple of nwg / 8 the phase of workgroup w depends on w mod 8
+        // only -- and so does its XCD (workgroup b is dispatched to XCD b % 8): every XCD's workgroups walk the operand IN
+        // STEP, one window of it is live per L2, and the operand lines of all but the first panel are L2 hits (TCC_MISS
+        // 23.1 M -> 12.6 M per u-pass: the streams alone; u-pass 448 -> 354 us, v-pass 358 -> 307 us on the config-5 shard,
+        // profiles/r04_exp_scatter_alignment.txt).  Two to four phases per XCD measure within 3 % of one.  Equal nnz per
+        // range is kept, so a skewed matrix only blurs the windows.  With panel groups every LAUNCH is aligned on its own:
+        // the panels of a group against the workgroups of its launch.  MFX_SCATTER_PANEL_MULT=0: round 3's panel count.
+        int dev = 0, cus = 0;
+        const char* mult_env = std::getenv("MFX_SCATTER_PANEL_MULT");
+        const bool align = !(mult_env && std::atoi(mult_env) == 0);
+        if (p->panel_rows == 0 && hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 16) {
+            uint32_t nwg = (uint32_t) cus;
+            if (is_csr && comm_reserve_cus_ > 0 && comm_reserve_cus_ + 8 <= nwg) { nwg = (nwg - comm_reserve_cus_) / 8 * 8; o.scatter_wgs = nwg; }
+            const uint32_t q = nwg / 8, p0 = (G + kScatterPanel - 1) / kScatterPanel;
+            auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+            uint32_t P = 0;
+            if (align && p0 >= q / 2 * groups) {  // enough panels for the operand to outgrow an L2 window
+                for (uint32_t c = (p0 + groups - 1) / groups * groups; c <= 2 * p0 + q * groups; c += groups)
+                    if (q / gcd(q, c / groups) <= 2) { P = c; break; }
             }
+            if (P == 0 && groups > 1 && p0 >= groups) P = (p0 + groups - 1) / groups * groups;  // equal groups at least
+            if (P) o.panel_rows = (G + P - 1) / P;
         }
         // spans of 4 tiles when the matrix is large: with persistent workgroups (ccd_scatter.hip) the span length only
         // sets the granularity of their chunk ranges and the padding at every panel's end -- 2 ... 14 tiles measure
@@ -738,7 +795,7 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
         try {
             rc_csr = use_device(device_);
             if (rc_csr == MFX_OK)
-                rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, options(m_, n_, kCsrSliceBytes),
+                rc_csr = csr_.build(m_, nnz_, n_, R->csr_row_ptr, R->csr_col_idx, R->csr_val, space, options(m_, n_, kCsrSliceBytes, true),
                                     scatter ? 2 : p->layout_build, st_);
         } catch (const std::exception& ex) {
             rc_csr = fail(MFX_ERR_ALLOC, "building the CSR copy failed: %s", ex.what());
@@ -747,7 +804,7 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
     });
     int rc_csc;
     try {
-        rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, options(n_, m_, sizeof(float2)),
+        rc_csc = csc_.build(n_, nnz_, m_, R->csc_col_ptr, R->csc_row_idx, R->csc_val, space, options(n_, m_, sizeof(float2), false),
                             scatter ? 2 : p->layout_build, st_);
     } catch (const std::exception& ex) {
         rc_csc = fail(MFX_ERR_ALLOC, "building the CSC copy failed: %s", ex.what());
@@ -791,21 +848,28 @@ int CcdSolver::finalize_cols(const FinalizeArgs& base) {
 
 // Slabs of the scatter pass that just ran -> dense (g, h) -> all-reduce over the shards (column side) ->
 // the ordinary finalize from a dense buffer.  `cols`: the sums are over columns (they came from csr_).
-int CcdSolver::scatter_finalize(bool cols, const FinalizeArgs& base) {
+int CcdSolver::scatter_finalize(bool cols, const FinalizeArgs& base, int group, hipStream_t st) {
+    if (!st) st = st_;
     SegStreamStore& src = cols ? csr_ : csc_;  // the store that was streamed; results are per its local dimension
     float* gh = cols ? gh_cols_.get() : gh_rows_.get();
-    PROF(KernelProfiler::K_SCAT_COMBINE, launch_scatter_combine(src.view, gh, st_));
-    FinalizeArgs f = base;
-    f.gh_dense = gh;
-    f.cnt_override = (cols ? csc_ : csr_).view.seg_cnt;  // |Omega| of the reduced dimension = the OTHER store's segment counts
-    if (cols && comm_) {
-        PROF(KernelProfiler::K_ALLREDUCE, comm_allreduce_f32(comm_, gh, (size_t) 2 * n_, st_));
-        f.cnt_override = global_col_nnz_.get();
-    }
+    const SegStreamDev& v = src.view;
     SegStreamDev out_view;  // finalize from a dense buffer only needs the length
     out_view.nseg = cols ? n_ : m_;
-    out_view.seg_cnt = f.cnt_override;
-    PROF(KernelProfiler::K_FINALIZE, launch_finalize(out_view, f, st_));
+    for (uint32_t g = group < 0 ? 0u : (uint32_t) group; g < (group < 0 ? v.scat_ngroups : (uint32_t) group + 1); ++g) {
+        const uint32_t lo = v.scat_grp_lo[g], hi = v.scat_grp_lo[g + 1];
+        if (hi <= lo) continue;
+        PROFS(KernelProfiler::K_SCAT_COMBINE, st, launch_scatter_combine(v, gh, st, (int) g));
+        FinalizeArgs f = base;
+        f.gh_dense = gh + 2 * (size_t) lo;  // the group's block: g of [lo, hi), then h
+        f.seg_base = lo; f.gh_len = hi - lo;
+        f.cnt_override = (cols ? csc_ : csr_).view.seg_cnt;  // |Omega| of the reduced dimension = the OTHER store's segment counts
+        if (cols && comm_) {
+            PROFS(KernelProfiler::K_ALLREDUCE, st, comm_allreduce_f32(comm_, gh + 2 * (size_t) lo, (size_t) 2 * (hi - lo), st));
+            f.cnt_override = global_col_nnz_.get();
+        }
+        out_view.seg_cnt = f.cnt_override;
+        PROFS(KernelProfiler::K_FINALIZE, st, launch_finalize(out_view, f, st));
+    }
     return MFX_OK;
 }
 
@@ -888,11 +952,25 @@ int CcdSolver::rank_fused_scatter(uint32_t t) {
     const uint32_t next = (t + 1) % k_;
     // same invariant as rank_fused: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old).
     // v-update: stream the ROW-major copy; columns are local (slice packB, accumulators), rows stream (packA)
-    PROF(KernelProfiler::K_SCAT_V, launch_scatter(SM_V, csr_.view, packB_.get(), packA_.get(), 0, st_));
     FinalizeArgs fv = fin_base();
     fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next); fv.pack4 = packC_.get();
     fv.pack4_as3 = true;  // 12-byte triples: a quarter fewer line fills of the streamed operand in the u-pass
-    MFX_TRY(scatter_finalize(true, fv));
+    if (overlap_groups_ > 1) {
+        // panel group g: pass on st_; its combine -> all-reduce -> finalize on st2_, under the pass of group g + 1.  A group's
+        // finalize writes H[t], packB and the triples for ITS columns only; the launches still to come read packB for
+        // theirs.  st_ joins st2_ before the u-pass, which needs every column's new value.
+        for (uint32_t g = 0; g < overlap_groups_; ++g) {
+            PROF(KernelProfiler::K_SCAT_V, launch_scatter(SM_V, csr_.view, packB_.get(), packA_.get(), 0, st_, (int) g));
+            MFX_HIP(hipEventRecord(ev_grp_[g], st_));
+            MFX_HIP(hipStreamWaitEvent(st2_, ev_grp_[g], 0));
+            MFX_TRY(scatter_finalize(true, fv, (int) g, st2_));
+        }
+        MFX_HIP(hipEventRecord(ev_join_, st2_));
+        MFX_HIP(hipStreamWaitEvent(st_, ev_join_, 0));
+    } else {
+        PROF(KernelProfiler::K_SCAT_V, launch_scatter(SM_V, csr_.view, packB_.get(), packA_.get(), 0, st_));
+        MFX_TRY(scatter_finalize(true, fv));
+    }
     // u-update: stream the COLUMN-major copy; rows are local (slice packA), columns stream (packC, triples)
     PROF(KernelProfiler::K_SCAT_U, launch_scatter(SM_U, csc_.view, packA_.get(), packC_.get(), 0, st_));
     FinalizeArgs fu = fin_base();
@@ -1114,6 +1192,14 @@ int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
         // take that hit before the first timed iteration, with an all-reduce of the (still zero) column
         // buffer.  Every rank reaches this point with the same n_outer, so the collective is matched.
         MFX_TRY(comm_allreduce_f32(comm_, gh_cols_.get(), (size_t) 2 * n_, st_));
+        if (overlap_groups_ > 1) {  // ... and the panel-group sized ones on the stream they will run on
+            const SegStreamDev& v = csr_.view;
+            MFX_HIP(hipStreamSynchronize(st_));
+            for (uint32_t g = 0; g < v.scat_ngroups; ++g)
+                if (v.scat_grp_lo[g + 1] > v.scat_grp_lo[g])
+                    MFX_TRY(comm_allreduce_f32(comm_, gh_cols_.get() + 2 * (size_t) v.scat_grp_lo[g], (size_t) 2 * (v.scat_grp_lo[g + 1] - v.scat_grp_lo[g]), st2_));
+            MFX_HIP(hipStreamSynchronize(st2_));
+        }
         MFX_HIP(hipStreamSynchronize(st_));
         comm_warm_ = true;
     }

@@ -48,6 +48,8 @@ private:
     DevBuf<uint32_t> segid_, slab_lo_, tile_base_, scat_chunk_lo_, scat_slab0_, scat_slab_bad_;  // scatter layout
     DevBuf<uint8_t> seg_delta_;
     DevBuf<unsigned long long> wgacc_;
+    uint32_t ngroups_ = 1, grp_nwg_[SegStreamDev::kMaxScatterGroups] = {}, grp_tab_[SegStreamDev::kMaxScatterGroups] = {},
+             grp_wg0_[SegStreamDev::kMaxScatterGroups] = {}, grp_lo_[SegStreamDev::kMaxScatterGroups + 1] = {};  // scatter panel groups
     // run-compressed provenance (perm_is_runs): kept on the host, uploaded on the first unpermute()
     std::vector<uint32_t> first_q_host_, panel_end_host_;
     DevBuf<uint32_t> first_q_dev_, panel_end_dev_;
@@ -134,7 +136,12 @@ private:
     // kernel_variant = -1: sweeps in the reference's summation order (ccd_reforder.hip), bit-identical to src/CCD.cpp
     bool ref_order_ = false;
     DevBuf<uint32_t> ref_order_csc_, ref_order_csr_;  // segments, longest first
-    int scatter_finalize(bool cols, const FinalizeArgs& base);  // slabs -> dense (g,h) -> [all-reduce] -> finalize
+    // slabs -> dense (g,h) -> [all-reduce] -> finalize, for one panel group of the streamed store (-1: all), on `st` (nullptr: st_)
+    int scatter_finalize(bool cols, const FinalizeArgs& base, int group = -1, hipStream_t st = nullptr);
+    // (r4) overlap of the column-side exchange with the column pass (sharded solve, scatter layout): see init()
+    uint32_t overlap_groups_ = 1, comm_reserve_cus_ = 0;
+    hipStream_t st2_ = nullptr;
+    hipEvent_t ev_grp_[SegStreamDev::kMaxScatterGroups] = {}, ev_join_ = nullptr;
     int rank_fused_scatter(uint32_t t);
     int finalize_cols(const FinalizeArgs& base);  // CSC side: all-reduce across shards if sharded
     int test_rmse(double* rmse_out);

@@ -151,6 +151,8 @@ struct FlatLayoutOptions {
     // partials; built by the device pipeline only
     bool scatter = false;
     bool scatter_ids32 = false;   // keep the 4-byte ids even when one-byte steps would do (A/B, tests)
+    uint32_t scatter_groups = 1;  // panel groups the pass can be launched by (ccd_kernels.hpp, SegStreamDev::scat_ngroups)
+    uint32_t scatter_wgs = 0;     // persistent workgroups per launch; 0 = one per CU
     const float* val = nullptr;   // input-order values for emit_val; nullptr = zeros
 };
 

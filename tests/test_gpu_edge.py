@@ -226,6 +226,47 @@ def test_scatter_persistent_workgroup_ranges(mfx, orc, monkeypatch, wgs):
     assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(ref, got))
 
 
+@pytest.mark.parametrize("groups,reserve", [(2, 0), (4, 16), (5, 8), (16, 0)])
+def test_scatter_overlap_groups_are_bit_identical(mfx, monkeypatch, groups, reserve):
+    """(r4) Sharded solve, scatter layout: the column pass launched panel group by panel group, with each group's combine ->
+    all-reduce -> finalize on a second stream under the next group's pass, on fewer workgroups (CUs left to the
+    collective).  The sums are fixed-point integers, so ANY grouping gives the bits of the unsplit pass: W, H and both
+    residual copies of a 1-rank RCCL solve with G groups equal those of the same solve with one group and of the
+    unsharded solve.  200 k x 30 k with explicit panels of 1500 (20 column panels) so that every group count is real."""
+    d = mfx.dataset.synth_ratings(200000, 30000, 1500000, seed=77, skew=0.3, test_frac=0.002)
+    k, t = 3, 2
+    W0 = mfx.initial_col(k, d.rows)
+    cnt = np.ascontiguousarray(np.diff(d.csc_col_ptr.astype(np.int64)).astype(np.uint32))
+
+    def solve(with_comm, T=1):
+        p = _p(mfx, k, t, T, kernel_variant=2, panel_rows=1500)
+        comm = mfx.Comm(mfx.Comm.unique_id(), 0, 1, 0) if with_comm else None
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), p, comm=comm, global_col_nnz=cnt if comm else None,
+                          global_test_nnz=d.nnz_test)
+        s.set_factors(W0.copy())
+        rep = s.iterate(t)
+        W, H = s.get_factors()
+        csc, csr = s.get_residual(d.nnz)
+        s.close()
+        if comm:
+            comm.close()
+        return W, H, csc, csr, np.array([r.rmse for r in rep])
+
+    monkeypatch.setenv("MFX_OVERLAP_GROUPS", "1")
+    ref = solve(False)
+    one = solve(True)
+    monkeypatch.setenv("MFX_OVERLAP_GROUPS", str(groups))
+    monkeypatch.setenv("MFX_COMM_RESERVE_CUS", str(reserve))
+    split = solve(True)
+    for a, b, c in zip(ref[:5], one[:5], split[:5]):
+        assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(a), bits(c))
+    split2 = solve(True, T=2)  # the read-only column sweeps of T = 2 run over the grouped store as well
+    monkeypatch.setenv("MFX_OVERLAP_GROUPS", "1")
+    one2 = solve(True, T=2)
+    for a, b in zip(one2[:5], split2[:5]):
+        assert np.array_equal(bits(a), bits(b))
+
+
 def test_scatter_non_finite_terms_are_not_silently_wrong(mfx):
     """the scatter pass accumulates in 64-bit fixed point, which cannot hold NaN / Inf / |x| >= 2^27.
     Such a term must not come back as a finite but wrong sum: the kernel flags the slab, the combine poisons the
