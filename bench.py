@@ -56,21 +56,23 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
-    """Secondary measurement (BASELINE configs[3]): ALS iteration time on the same synthetic matrix."""
-    import numpy as np
-    host = synth_torch.to_rating_data(d)
+def als_measure(a, d, mfx, k, steps, warmup) -> dict:
+    """ALS iterations (BASELINE configs[3]) on the device-resident matrix `d`: time per iteration, the two half-sweeps
+    against both of their rooflines, test RMSE."""
+    import time as _t
+    import torch
     p = mfx.parameter()
-    p.k, p.lambda_ = a.k, a.lam
-    s = mfx.AlsSolver(host, mfx.test_data_of(host), p)
-    s.set_factors(mfx.initial_col(host.cols, a.k))
-    s.iterate(a.warmup, with_rmse=False)
+    p.k, p.lambda_ = k, a.lam
+    s = mfx.AlsSolver(None, None, p, device_arrays=d)
+    rows, cols, Z = int(d["rows"]), int(d["cols"]), int(d["csr_val"].numel())
+    s.set_factors(mfx.initial_col(cols, k))
+    s.iterate(warmup, with_rmse=False)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rep = s.iterate(a.steps, with_rmse=True)
-    el = time.perf_counter() - t0
+    t0 = _t.perf_counter()
+    rep = s.iterate(steps, with_rmse=True)
+    el = _t.perf_counter() - t0
     kt = s.kernel_times()
-    Z, k = host.nnz, a.k
+    s.close()
     flops = 2.0 * (Z * k * (k + 1) + 2.0 * Z * k)  # both half-sweeps: symmetric Gramian + rhs
     # Per half-sweep: the matrix-core roofline (Z k (k + 1) + 2 Z k flop of symmetric Gramian + rhs) AND the gather
     # roofline -- SURVEY 8d: Z (8 + 4 k) bytes per half-sweep (index + rating + one k-float factor row per rating).  The
@@ -96,19 +98,28 @@ def bench_als(a, d, mfx, synth_torch, torch, gen_s) -> None:
             traffic_source = "stale: als_solver.hip changed since profiles/traffic.json was collected"
     except Exception:
         pass
-    print(json.dumps({"metric": "ALS iteration time at k=%d" % k, "value": round(1e3 * el / a.steps, 3), "unit": "ms",
+    ms = 1e3 * el / steps
+    return {"ms_per_iteration": round(ms, 3), "k": k, "steps": steps, "warmup": warmup, "workload": f"{rows}x{cols} nnz={Z} k={k}",
+            "gramian_tflops": round(flops / (el / steps) / 1e12, 2),
+            # whole iteration (Gramians + 2 x nseg Cholesky/solves) against the fp32 MFMA peak,
+            # counting only the symmetric half of each Gramian as useful work
+            "roofline": {"bound": "mfma", "achieved": round(flops / (el / steps) / 1e12, 2), "peak": 157.3,
+                         "unit": "TFLOP/s", "frac": round(flops / (el / steps) / 1e12 / 157.3, 4), "traffic": traffic,
+                         "traffic_source": traffic_source},
+            "half_sweeps": halves,
+            "kernels": {n: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1])} for n, v in kt.items()},
+            "rmse": [round(r.rmse, 6) for r in rep], "als_src_sha16": als_source_hash()}
+
+
+def bench_als(a, d, mfx, gen_s) -> None:
+    """Secondary measurement (BASELINE configs[3]): ALS iteration time on the same synthetic matrix, as its own line."""
+    m = als_measure(a, d, mfx, a.k, a.steps, a.warmup)
+    print(json.dumps({"metric": "ALS iteration time at k=%d" % a.k, "value": m["ms_per_iteration"], "unit": "ms",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "higher_is_better": False, "dtype": "f32",
-                      "data": "synthetic", "config": {"workload": f"{host.rows}x{host.cols} nnz={Z} k={k}"},
-                      "gramian_tflops": round(flops / (el / a.steps) / 1e12, 2),
-                      # whole iteration (Gramians + 2 x nseg Cholesky/solves) against the fp32 MFMA peak,
-                      # counting only the symmetric half of each Gramian as useful work
-                      "roofline": {"bound": "mfma", "achieved": round(flops / (el / a.steps) / 1e12, 2), "peak": 157.3,
-                                   "unit": "TFLOP/s", "frac": round(flops / (el / a.steps) / 1e12 / 157.3, 4), "traffic": traffic,
-                                   "traffic_source": traffic_source},
-                      "half_sweeps": halves,
-                      "kernels": {n: {"total_ms": round(v[0] * 1e3, 3), "launches": int(v[1])} for n, v in kt.items()},
-                      "rmse": [round(r.rmse, 6) for r in rep], "gen_seconds": round(gen_s, 2)}), flush=True)
-    s.close()
+                      "data": "synthetic", "config": {"workload": m["workload"]},
+                      "gramian_tflops": m["gramian_tflops"], "roofline": m["roofline"], "half_sweeps": m["half_sweeps"],
+                      "kernels": m["kernels"], "rmse": m["rmse"], "als_src_sha16": m["als_src_sha16"],
+                      "gen_seconds": round(gen_s, 2)}), flush=True)
 
 
 def kernel_source_hash() -> str:
@@ -116,9 +127,13 @@ def kernel_source_hash() -> str:
     to the kernels it was measured on (tools/collect_profiles.py writes the same value)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("ccd_kernels.hip", "ccd_scatter.hip", "flat_layout.hpp"):
+    for f in CCD_HASHED_SOURCES:
         h.update(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+# (layout choices -- panel counts, workgroup ranges -- live in ccd_solver.hip / layout_kernels.hip and move the traffic too)
+CCD_HASHED_SOURCES = ("ccd_kernels.hip", "ccd_scatter.hip", "flat_layout.hpp", "ccd_solver.hip", "layout_kernels.hip")
 
 
 def als_source_hash() -> str:
@@ -197,7 +212,90 @@ def dry_run(a) -> None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t[0]), "workload": a.workload}), flush=True)
+        out = {"dry_run": True, "n_gpus": world, "rank_sum": float(t[0]), "workload": a.workload}
+        if world > 1 and a.workload == "netflix" and not a.no_strong:  # what the real run adds at N > 1 (same keys, no values)
+            out["config5_strong"] = {k: None for k in CONFIG5_STRONG_KEYS}
+        print(json.dumps(out), flush=True)
+
+
+CONFIG5_STRONG_KEYS = ("workload", "scaling", "k", "steps", "warmup", "ms_per_step", "value", "unit", "overlap_groups", "by_overlap_groups",
+                       "allreduce_us_per_inner_iter", "host_enqueue_ms_per_step", "rank_nnz_min", "rank_nnz_max", "speedup_vs_n1",
+                       "n1_ms_per_step", "n1_source", "layout", "gen_seconds")
+
+
+def config5_strong_leg(a, torch, dist, mfx, synth_torch, comm, world, rank, local_rank, dev) -> dict:
+    """(r4) The north star's OWN scaling workload on the ranks of an N > 1 run, next to the weak-scaling headline: BASELINE
+    configs[4] -- ONE global 10 M x 1 M matrix with 1e9 ratings, k = 128, nnz-balanced user-row blocks, one 8 MB all-reduce
+    of the column partials per inner iteration -- timed for a.strong_steps outer iterations per setting of the
+    panel-group overlap (MFX_OVERLAP_GROUPS = 1: the exchange fully exposed; 2: the first half of the columns is
+    exchanged under the second half's pass).  The better one is the leg's value; both are listed.  speedup_vs_n1 is against
+    the committed single-GPU record of the same workload (profiles/, named in n1_source)."""
+    t0 = time.time()
+    rows, cols, nnz, k = 10_000_000, 1_000_000, 1_000_000_000, 128
+    d = synth_torch.synth_ratings_device(rows, cols, nnz, seed=a.seed, device=dev, sigma_rows=0.5, sigma_cols=1.0, shard=(rank, world))
+    nnz_local = int(d["csr_val"].numel())
+    col_cnt = (d["csc_col_ptr"][1:] - d["csc_col_ptr"][:-1]).to(torch.int32).contiguous()
+    tot = torch.tensor([nnz_local, int(d["test_val"].numel())], dtype=torch.int64, device=dev)
+    lo, hi = tot[:1].clone(), tot[:1].clone()
+    dist.all_reduce(col_cnt); dist.all_reduce(tot)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    W0 = mfx.initial_col(k, int(d["rows"]))
+    by, layout = {}, None
+    saved = os.environ.get("MFX_OVERLAP_GROUPS")
+    for groups in (1, 2):
+        os.environ["MFX_OVERLAP_GROUPS"] = str(groups)
+        p = mfx.parameter()
+        p.k, p.lambda_, p.maxinneriter, p.device = k, a.lam, 1, local_rank
+        solver, status = None, 0
+        try:
+            solver = mfx.CcdSolver(None, None, p, comm=comm, global_col_nnz=col_cnt, global_test_nnz=int(tot[1]), device_arrays=d)
+        except mfx.MfxError as ex:
+            status = -1
+            print(f"[rank {rank}] config5_strong: solver creation failed: {ex}", file=sys.stderr, flush=True)
+        if comm.agree(status) != 0:
+            raise SystemExit(f"[rank {rank}] config5_strong: a rank failed during setup")
+        layout = solver.layout_info()
+        solver.set_factors(W0)
+        solver.iterate(1, with_rmse=False)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        solver.iterate(a.strong_steps, with_rmse=False)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        te = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        ms = 1e3 * float(te[0]) / a.strong_steps
+        solver.set_profile(True)
+        solver.iterate(1, with_rmse=False)
+        kt = solver.kernel_times()
+        solver.close()
+        avg = lambda n: round(kt[n][0] / max(1, kt[n][1]) * 1e6, 2) if n in kt else None
+        by[str(groups)] = {"ms_per_step": round(ms, 3), "allreduce_us": avg("rccl_allreduce"), "allreduce_calls_per_step": int(kt["rccl_allreduce"][1]) if "rccl_allreduce" in kt else 0,
+                           "v_pass_us": avg("ccd_scatter_v_pass"), "u_pass_us": avg("ccd_scatter_u_pass"),
+                           "host_enqueue_ms_per_step": round(kt["host_enqueue_outer_iteration"][0] * 1e3, 3) if "host_enqueue_outer_iteration" in kt else None}
+    if saved is None:
+        os.environ.pop("MFX_OVERLAP_GROUPS", None)
+    else:
+        os.environ["MFX_OVERLAP_GROUPS"] = saved
+    best = min(by, key=lambda g: by[g]["ms_per_step"])
+    ms = by[best]["ms_per_step"]
+    n1_ms, n1_src = None, "none: no committed single-GPU record of this workload under profiles/"
+    for f in ("r04_bench_config5.json", "r03_bench_config5.json"):
+        try:
+            n1_ms = float(json.load(open(os.path.join(ROOT, "profiles", f)))["ms_per_step"])
+            n1_src = f"profiles/{f} (bench.py --workload config5 --gpus 1, builder-run)"
+            break
+        except Exception:
+            continue
+    return {"workload": f"synthetic (BASELINE configs[4]): ONE global {rows}x{cols}, nnz={int(tot[0])}, k={k}, T=1, nnz-balanced user-row blocks over {world} GPUs",
+            "scaling": "strong", "k": k, "steps": a.strong_steps, "warmup": 1, "ms_per_step": ms, "value": round(int(tot[0]) / (ms * 1e-3), 1), "unit": "nnz/s",
+            "overlap_groups": int(best), "by_overlap_groups": by,
+            "allreduce_us_per_inner_iter": by[best]["allreduce_us"] * by[best]["allreduce_calls_per_step"] / k if by[best]["allreduce_us"] is not None else None,
+            "host_enqueue_ms_per_step": by[best]["host_enqueue_ms_per_step"],
+            "rank_nnz_min": int(lo[0]), "rank_nnz_max": int(hi[0]),
+            "speedup_vs_n1": round(n1_ms / ms, 3) if n1_ms else None, "n1_ms_per_step": n1_ms, "n1_source": n1_src,
+            "layout": layout, "gen_seconds": round(gen_s, 2)}
 
 
 def main() -> None:
@@ -228,6 +326,9 @@ def main() -> None:
                     help="skip the second, event-bracketed pass (use under rocprofv3 --kernel-trace: the "
                          "event packets between launches otherwise end up inside its kernel durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-als", action="store_true", help="skip the ALS leg (configs[3], 3 iterations at k = 64 on the resident matrix; N = 1, default workload only)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1, default workload: skip the config5_strong leg (configs[4] on the same ranks)")
+    ap.add_argument("--strong-steps", type=int, default=2, help="timed outer iterations of the config5_strong leg, per overlap setting")
     ap.add_argument("--no-rank-one", action="store_true",
                     help="skip the standalone rank-one sweep measurement (one extra outer iteration at T = 2, N = 1 only)")
     ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
@@ -304,7 +405,7 @@ def main() -> None:
     gen_s = time.time() - t0
 
     if a.solver == "als":
-        return bench_als(a, d, mfx, synth_torch, torch, gen_s)
+        return bench_als(a, d, mfx, gen_s)
     p = mfx.parameter()
     p.k, p.lambda_, p.maxinneriter, p.device = a.k, a.lam, a.inner, local_rank
     p.schedule, p.kernel_variant, p.tiles_per_span = a.schedule, a.variant, a.tiles
@@ -450,6 +551,14 @@ def main() -> None:
                         "unit": "GB/s", "frac": round(b_r1 / avg / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "standalone v-/u-sweep launches of one outer iteration at T = 2 (inner iteration 2)"}
 
+    # ---------------- ALS (BASELINE configs[3]) on the same resident matrix: 3 iterations at k = 64 ----------------
+    als = None
+    if world == 1 and not a.no_als and a.workload == "netflix" and a.k == 64 and a.schedule == 1 and not a.no_event_pass:
+        solver.close()
+        m_als = als_measure(a, d, mfx, 64, 3, 1)
+        als = {"ms_per_iteration": m_als["ms_per_iteration"], "k": 64, "steps": 3, "warmup": 1, "workload": m_als["workload"],
+               "roofline": m_als["roofline"], "half_sweeps": m_als["half_sweeps"], "rmse": m_als["rmse"], "als_src_sha16": m_als["als_src_sha16"]}
+
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N = 1 only) --------
     cpu_baseline = None
     if world == 1 and not a.no_cpu_baseline:
@@ -473,6 +582,14 @@ def main() -> None:
                                    f"({host.rows} rows, {host.nnz} ratings)") +
                                   f"; steady-state iteration 2 ({t_steady:.2f} s) scaled by {a.k}/{ks}"}
     solver.close()  # (idempotent)
+    rows_per_gpu = int(d["rows"])
+
+    # ---------------- N > 1: the strong-scaling workload of the north star on the same ranks ----------------
+    strong = None
+    if world > 1 and a.workload == "netflix" and not a.no_strong:
+        del d, col_cnt
+        torch.cuda.empty_cache()
+        strong = config5_strong_leg(a, torch, dist, mfx, synth_torch, comm, world, rank, local_rank, dev)
 
     if rank == 0:
         if strong:
@@ -493,10 +610,11 @@ def main() -> None:
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label,
-                       "rows_per_gpu": int(d["rows"]), "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
+                       "rows_per_gpu": rows_per_gpu, "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
                        "inner_iters": a.inner, "schedule": "fused" if a.schedule == 1 else "as-written",
                        "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},
-            "roofline": roofline, "rank_one_kernel": rank_one, "cpu_baseline": cpu_baseline, "kernels": kernels,
+            "roofline": roofline, "rank_one_kernel": rank_one, "cpu_baseline": cpu_baseline, "als": als, "config5_strong": strong,
+            "kernel_src_sha16": kernel_source_hash(), "als_src_sha16": als_source_hash(), "kernels": kernels,
             "allreduce_us_per_inner_iter": (kernels["rccl_allreduce"]["avg_us"] if "rccl_allreduce" in kernels else None),
             # host time to enqueue one outer iteration's launches (+ collectives) in the event-bracketed pass, next to the
             # GPU time of the same iteration: while it is smaller, launch cost is hidden behind the running kernels (the

@@ -1225,6 +1225,7 @@ int AlsSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
 // After a half-sweep every rank holds only its own block of the factor it just solved: ONE grouped exchange
 // (every owner broadcasts its block inside a single ncclGroupStart / End) makes the replica whole again.
 int AlsSolver::exchange(float* X, const std::vector<int64_t>& bounds) {
+    MFX_REQUIRE(shards_met_ && bounds.size() == (size_t) comm_->nranks + 1, "ALS exchange without validated shard boundaries");
     std::vector<int64_t> elems(bounds.size());
     for (size_t r = 0; r < bounds.size(); ++r) elems[r] = bounds[r] * (int64_t) k_;
     return comm_allgather_blocks_f32(comm_, X, elems.data(), st_);
@@ -1232,10 +1233,21 @@ int AlsSolver::exchange(float* X, const std::vector<int64_t>& bounds) {
 
 // First iterate() of a sharded solve: everyone's block boundaries.  Every rank sees the same gathered vector, so a
 // partition that is not contiguous in rank order or does not cover the matrix fails on ALL ranks alike.
+// The boundaries are gathered into LOCAL vectors and become the solver's only after every check has passed: a failed
+// first iterate() (not contiguous / does not cover) must leave the solver in the state "not met" -- round 3 keyed on
+// row_bounds_.empty(), which gather_bounds had already filled, so a second iterate() went on to exchange() with
+// unvalidated (or, for the columns, missing) boundaries.
 int AlsSolver::meet_shards() {
-    MFX_TRY(gather_bounds(comm_, row_lo_, row_hi_, &row_bounds_, st_));
-    MFX_TRY(gather_bounds(comm_, col_lo_, col_hi_, &col_bounds_, st_));
-    MFX_REQUIRE(row_bounds_.back() == (int64_t) m_ && col_bounds_.back() == (int64_t) n_, "ALS shards do not cover the matrix");
+    shards_met_ = false;
+    std::vector<int64_t> rb, cb;
+    MFX_TRY(gather_bounds(comm_, row_lo_, row_hi_, &rb, st_));
+    MFX_TRY(gather_bounds(comm_, col_lo_, col_hi_, &cb, st_));
+    const size_t want = (size_t) comm_->nranks + 1;
+    MFX_REQUIRE(rb.size() == want && cb.size() == want, "ALS shards: gathered %zu / %zu boundaries for %d ranks", rb.size(), cb.size(), comm_->nranks);
+    MFX_REQUIRE(rb.back() == (int64_t) m_ && cb.back() == (int64_t) n_, "ALS shards do not cover the matrix");
+    row_bounds_.swap(rb);
+    col_bounds_.swap(cb);
+    shards_met_ = true;
     return MFX_OK;
 }
 
@@ -1268,7 +1280,7 @@ int AlsSolver::iterate(int n_iter, int with_rmse, mfx_iter_report* reports) {
     MFX_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
     MFX_REQUIRE(factors_set_, "mfx_als_iterate: call mfx_als_set_factors first");
     MFX_TRY(use_device(device_));
-    if (comm_ && row_bounds_.empty() && n_iter > 0) MFX_TRY(meet_shards());
+    if (comm_ && !shards_met_ && n_iter > 0) MFX_TRY(meet_shards());
     for (int it = 0; it < n_iter; ++it) {
         MFX_HIP(hipMemsetAsync(spd_fail_.get(), 0, sizeof(uint32_t), st_));
         MFX_HIP(hipEventRecord(ev_[0], st_));

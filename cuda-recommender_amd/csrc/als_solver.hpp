@@ -58,6 +58,7 @@ private:
     mfx_comm_s* comm_ = nullptr;
     uint32_t row_lo_ = 0, col_lo_ = 0, row_hi_ = 0, col_hi_ = 0;
     std::vector<int64_t> row_bounds_, col_bounds_;
+    bool shards_met_ = false;  // both boundary vectors gathered AND validated (meet_shards)
     int64_t global_test_nnz_ = 0;
     AlsHalf rows_, cols_;
     DevBuf<float> W_, H_, ws_;

@@ -649,7 +649,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // SIMD lane), so the column pass leaves `reserve` CUs free.  MFX_OVERLAP_GROUPS (1 = off) / MFX_COMM_RESERVE_CUS.
     if (shard && shard->comm) {
         const int nr = shard->comm->nranks;
-        int groups = nr > 1 ? 4 : 1, reserve = -1;
+        int groups = nr > 1 ? 2 : 1, reserve = -1;
         if (const char* e = std::getenv("MFX_OVERLAP_GROUPS")) groups = std::atoi(e);
         if (const char* e = std::getenv("MFX_COMM_RESERVE_CUS")) reserve = std::atoi(e);
         overlap_groups_ = (uint32_t) std::max(1, std::min(groups, (int) SegStreamDev::kMaxScatterGroups));

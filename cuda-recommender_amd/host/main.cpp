@@ -115,6 +115,10 @@ int main(int argc, char* argv[]) {
         second.schedule = 0;         // ALS: als_exact.hip; CCD++: one launch per reference kernel ...
         second.kernel_variant = -1;  // ... with the sweeps in the reference's summation order (ccd_reforder.hip)
         second.n_gpus = 1;           // a sharded sum has no reference order
+        if (second.libpmf_flags) {   // -e / -N change the arithmetic: the reference ignores them, and so does its stand-in leg
+            puts("[INFO] -OMP: the reference ignores -e / -N / -p / -q (src/pmf.h:33-36); the reference-order leg runs without -libpmf_flags.");
+            second.libpmf_flags = 0;
+        }
         const Stopwatch sw;
         solve_on_gpu(R, T, untouched, second, als);
         printf("[info] reference-order GPU leg training time: %lf s.\n", sw.seconds());
@@ -134,8 +138,10 @@ int main(int argc, char* argv[]) {
     if (model_path) {
         FILE* fp = fopen(model_path, "wb");
         if (!fp) { fprintf(stderr, "can't open model file %s\n", model_path); return EXIT_FAILURE; }
-        save_mat_t(solved.W, fp, als);
-        save_mat_t(solved.H, fp, als);
+        // the -CUDA leg's factors (src/main.cpp:146-147 saves W_cuda / H_cuda); with -OMP alone, the reference-order leg's
+        const Factors& out = prm.enable_cuda || !prm.enable_omp ? solved : untouched;
+        save_mat_t(out.W, fp, als);
+        save_mat_t(out.H, fp, als);
         fclose(fp);
         printf("[info] model written to %s\n", model_path);
     }

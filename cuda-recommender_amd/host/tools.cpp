@@ -163,7 +163,7 @@ void exit_with_help() {
            "    -schedule s : 1 fused passes (default), 0 one launch per reference kernel\n"
            "    -panel rows : LDS panel size, 0 auto, -1 off\n"
            "    -nGPUs n : CCD++ over n user-row-block shards, one GPU each (RCCL all-reduce per inner iteration)\n"
-           "    -save file : write W then H in the reference's model format (save_mat_t)\n"
+           "    -save file : write W then H in the reference's model format (save_mat_t); with -OMP alone: the reference-order leg's\n"
            "    -libpmf_flags 1 : honour -e, -N and -p/-q with their LIBPMF 1.41 meaning (CCD++, one GPU): function-decrease\n"
            "                      stopping rule, non-negative factors, per-rank test RMSE lines.  Default 0: parsed and\n"
            "                      ignored, like the reference does\n");

@@ -429,12 +429,24 @@ class AlsSolver:
     """Resident ALS (mfx_als_*)."""
 
     def __init__(self, R: RatingData, T, parameters: parameter, comm: Optional[Comm] = None,
-                 row_range=None, col_range=None):
+                 row_range=None, col_range=None, device_arrays: Optional[dict] = None):
         """With `comm`: rank-local ALS shard of the GLOBAL matrix R -- this rank solves user rows
-        row_range for the W-half and item columns col_range for the H-half (mfx_als_create_sharded)."""
+        row_range for the W-half and item columns col_range for the H-half (mfx_als_create_sharded).
+        device_arrays: the matrix as a dict of device tensors (mfx.synth_torch), single GPU only."""
         self.handle = C.c_void_p()
-        self.rows, self.cols, self.k = R.rows, R.cols, int(parameters.k)
         cp = parameters.to_c()
+        if device_arrays is not None:
+            assert comm is None, "device-resident inputs: single-GPU ALS only"
+            d = device_arrays
+            ptr = lambda t: C.c_void_p(int(t.data_ptr())) if t is not None and t.numel() else None
+            self.rows, self.cols, self.k = int(d["rows"]), int(d["cols"]), int(parameters.k)
+            csx = L.mfx_csx(self.rows, self.cols, int(d["csr_val"].numel()), ptr(d["csc_col_ptr"]), ptr(d["csc_row_idx"]), ptr(d["csc_val"]),
+                            ptr(d["csr_row_ptr"]), ptr(d["csr_col_idx"]), ptr(d["csr_val"]))
+            tv = d.get("test_val")
+            coo = L.mfx_coo(int(tv.numel()) if tv is not None else 0, ptr(d.get("test_row")), ptr(d.get("test_col")), ptr(tv))
+            L.check(L.lib().mfx_als_create(C.byref(self.handle), C.byref(csx), C.byref(coo), C.byref(cp), L.MFX_DEVICE))
+            return
+        self.rows, self.cols, self.k = R.rows, R.cols, int(parameters.k)
         if comm is None:
             csx, coo = _csx(R), _coo(T)
             L.check(L.lib().mfx_als_create(C.byref(self.handle), C.byref(csx), C.byref(coo), C.byref(cp), L.MFX_HOST))

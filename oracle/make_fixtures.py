@@ -92,6 +92,8 @@ def main() -> None:
                         W=rd(odir, "W.bin", shW), H=rd(odir, "H.bin", shH),
                         rmse=np.array([float(x) for x in re.findall(r"RMSE=([0-9]+\.[0-9]+|nan|-nan|inf)", txt)]),
                         final_rmse=np.array([float(re.search(r"Test RMSE = ([0-9]+\.[0-9]+|nan|-nan)", txt).group(1))]))
+                    # the reference's save_mat_t output for these factors, as raw bytes (the -save / -predict file format)
+                    res[threads]["model"] = np.fromfile(os.path.join(odir, "model.bin"), dtype=np.uint8)
                     if mode == "ccd":
                         res[threads]["csc_val_final"] = rd(odir, "csc_val_final.bin")
                         res[threads]["csr_val_final"] = rd(odir, "csr_val_final.bin")

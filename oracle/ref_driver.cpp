@@ -24,6 +24,17 @@ static void dump_f32(const std::string& path, const float* p, size_t n) {
     fclose(f);
 }
 
+/* The model file as the reference would write it: its OWN save_mat_t (src/tools.cpp:90-118), called the way its
+ * driver's (commented-out) call site does -- save_mat_t(W, model_fp, ifALS); save_mat_t(H, model_fp, ifALS);
+ * (src/main.cpp:146-147) -- on the factors the reference's solver just produced.  Pins the byte format of -save / -predict. */
+static void dump_model(const std::string& path, const MatData& W, const MatData& H, bool ifALS) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { perror(path.c_str()); exit(2); }
+    save_mat_t(W, f, ifALS);
+    save_mat_t(H, f, ifALS);
+    fclose(f);
+}
+
 static void dump_mat(const std::string& path, const MatData& M) {
     FILE* f = fopen(path.c_str(), "wb");
     if (!f) { perror(path.c_str()); exit(2); }
@@ -61,6 +72,7 @@ int main(int argc, char** argv) {
         dump_mat(out + "H.bin", H);
         dump_f32(out + "csc_val_final.bin", R.get_csc_val(), R.nnz);
         dump_f32(out + "csr_val_final.bin", R.get_csr_val(), R.nnz);
+        dump_model(out + "model.bin", W, H, false);
         calculate_rmse_directly(W, H, T, k, false);
     } else if (mode == "als") {
         initial_col(W, R.rows, k);
@@ -70,6 +82,7 @@ int main(int argc, char** argv) {
         ALS_OMP(R, W, H, T, param);
         dump_mat(out + "W.bin", W);
         dump_mat(out + "H.bin", H);
+        dump_model(out + "model.bin", W, H, true);
         calculate_rmse_directly(W, H, T, k, true);
     } else if (mode == "steps") {
         /* ---- CCD single steps, from the CCD-layout initial factors ---- */

@@ -226,13 +226,20 @@ def test_failing_als_shard_does_not_strand_the_others(mfx):
             res[r] = "finished"
         except mfx.MfxError as e:
             res[r] = "error: " + str(e)
+        # (r4) a SECOND iterate after the failed one validates again (every rank gathers again and fails alike): the failed
+        # attempt must not leave half-filled boundary vectors behind that the next call would exchange with
+        try:
+            sv.iterate(1)
+            res[r] += " | then finished"
+        except mfx.MfxError as e:
+            res[r] += " | again: " + str(e)
         sv.close(); comm.close()
 
     th = [threading.Thread(target=run, args=(r,)) for r in range(nranks)]
     [x.start() for x in th]
     [x.join(timeout=120) for x in th]
     assert not any(x.is_alive() for x in th), res
-    assert all(isinstance(x, str) and "not contiguous" in x for x in res), res
+    assert all(isinstance(x, str) and x.count("not contiguous") == 2 and "finished" not in x for x in res), res
 
 
 def _solve_f64(ptr, idx, val, X, k, lam):

@@ -196,15 +196,38 @@ def test_cli_gpu_path_fails_loudly_without_gpu(mfx, tmp_path):
     assert "[info] CUDA Training time:" in r.stdout
 
 
-def test_model_file_format_roundtrip(tmp_path):
-    """save_mat_t layout: [long m][long n][m*n float32 row-major] (src/tools.cpp:90-118)."""
+@pytest.mark.parametrize("tag", ["ccd_T1", "als"])
+def test_reference_model_file_loads_through_predict(tmp_path, tag):
+    """(N2, pinned) tests/golden/*.npz hold the bytes the REFERENCE's own save_mat_t (src/tools.cpp:90-118) wrote for its
+    final factors -- save_mat_t(W, fp, ifALS); save_mat_t(H, fp, ifALS) as at src/main.cpp:146-147, called by
+    oracle/ref_driver.cpp.  Format facts, checked against the factors of the same fixture: two native longs (m, n), then
+    m * n floats; with ifALS the matrix itself (rows x k), without it the k x rows CCD++ factor TRANSPOSED -- so both files
+    read as rows x k row-major, which is what calculate_rmse_from_file (src/extras.cpp:143-180) loads.  Product code
+    under test: mfx_train -predict (load_mat_t + the scoring loop) on the reference's bytes."""
     import struct
-    W = np.arange(12, dtype=np.float32).reshape(3, 4)
-    with open(tmp_path / "m.bin", "wb") as f:
-        f.write(struct.pack("<qq", 3, 4)); f.write(W.tobytes())
-    raw = open(tmp_path / "m.bin", "rb").read()
+    g, d = load_golden("small")
+    raw = g[tag + "__model"].tobytes()
+    k = int(g["k"][0])
+    W, H = g[tag + "__W"], g[tag + "__H"]
+    if tag == "ccd_T1":
+        W, H = W.T, H.T  # stored k x rows
     m, n = struct.unpack("<qq", raw[:16])
-    assert (m, n) == (3, 4) and np.array_equal(np.frombuffer(raw[16:], np.float32).reshape(3, 4), W)
+    assert (m, n) == (d.rows, k)
+    off = 16 + 4 * m * n
+    assert np.array_equal(np.frombuffer(raw[16:off], np.float32).reshape(m, n), W)
+    m2, n2 = struct.unpack("<qq", raw[off:off + 16])
+    assert (m2, n2) == (d.cols, k) and len(raw) == off + 16 + 4 * m2 * n2
+    assert np.array_equal(np.frombuffer(raw[off + 16:], np.float32).reshape(m2, n2), H)
+    (tmp_path / "model").write_bytes(raw)
+    trip = list(zip(d.test_row.tolist(), d.test_col.tolist(), d.test_val.tolist()))
+    (tmp_path / "test.txt").write_text("".join(f"{i + 1} {j + 1} {v!r}\n" for i, j, v in trip))  # 1-based, src/extras.cpp:169
+    r = _run_cli(["-predict", str(tmp_path / "model"), str(tmp_path / "test.txt"), str(tmp_path / "out.txt")])
+    assert r.returncode == 0, r.stderr
+    pred = np.array([float(x) for x in (tmp_path / "out.txt").read_text().split()])
+    want = np.array([float(np.dot(W[i].astype(np.float64), H[j].astype(np.float64))) for i, j, _ in trip])
+    assert np.allclose(pred, want, atol=1e-5)
+    rmse = float(np.sqrt(np.mean((want - np.array([v for *_, v in trip])) ** 2)))
+    assert f"[FINAL INFO] Test RMSE = {rmse:f}" in r.stdout
 
 
 def test_cli_predict_from_model_file(mfx, tmp_path):

@@ -1,21 +1,70 @@
 #!/usr/bin/env python3
-"""Copies the judged summaries of tools/prof_r03_final.sh from gpurun_out/final/<tag>/ into profiles/<round>_* and
+"""Copies the judged summaries of tools/prof_final.sh from gpurun_out/final/<tag>/ into profiles/<round>_* and
 rebuilds profiles/traffic.json: HBM bytes per launch of the dominant kernels from the FETCH_SIZE / WRITE_SIZE passes,
-each entry tied to the shape it was measured at, the date and the hash of the kernel sources (bench.py only quotes an
-entry whose hash matches the sources it runs from).        usage: collect_profiles.py r03"""
-import csv, datetime, glob, hashlib, json, os, subprocess, sys
+each entry tied to the shape it was measured at, the date and the hash of the kernel sources IT WAS MEASURED ON.
+
+(r4) Provenance.  bench.py prints `kernel_src_sha16` / `als_src_sha16` -- computed from the sources it runs next to -- in every
+JSON line; every profiled run of a workload directory (bench.log, stats.log, pmc_*.log) therefore carries the hash of the
+build it measured.  The collector takes the hash FROM THOSE LOGS, never from the working tree; it REFUSES a workload whose
+logs disagree with each other or with the tree (exit status 2, nothing of that workload is copied or recorded), and it never
+re-stamps an existing entry: an entry whose raw counter values are unchanged is kept as it is, hash and date included.
+(Round 3 stamped the tree's hash at collection time on counters that had been measured on a reverted experimental build.)
+usage: collect_profiles.py r04 [--src gpurun_out/final] [--dst profiles]"""
+import argparse, csv, datetime, glob, hashlib, json, os, subprocess, sys
 csv.field_size_limit(1 << 30)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src, dst = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+_ap = argparse.ArgumentParser()
+_ap.add_argument("tag", nargs="?", default="r04")
+_ap.add_argument("--src", default=os.path.join(ROOT, "gpurun_out", "final"))
+_ap.add_argument("--dst", default=os.path.join(ROOT, "profiles"))
+_args = _ap.parse_args()
+src, dst, tag = _args.src, _args.dst, _args.tag
 os.makedirs(dst, exist_ok=True)
+CCD_HASHED_SOURCES = ("ccd_kernels.hip", "ccd_scatter.hip", "flat_layout.hpp", "ccd_solver.hip", "layout_kernels.hip")  # = bench.py's
 
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ("ccd_kernels.hip", "ccd_scatter.hip", "flat_layout.hpp"):
+    for f in CCD_HASHED_SOURCES:
         h.update(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def als_source_hash():
+    return hashlib.sha256(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", "als_solver.hip"), "rb").read()).hexdigest()[:16]
+
+
+def run_hashes(d, key):
+    """The values of `key` in the bench JSON lines of every log of run directory d: {log name: hash}."""
+    out = {}
+    for f in sorted(glob.glob(os.path.join(d, "*.log"))):
+        for l in open(f, errors="replace"):
+            if l.startswith("{") and key in l:
+                try:
+                    out[os.path.basename(f)] = json.loads(l).get(key)
+                except Exception:
+                    pass
+    return out
+
+
+refused = []
+
+
+def provenance(d, wl, key, tree_hash):
+    """The one hash all logs of d agree on, if it is also the tree's; otherwise None and a refusal on stderr."""
+    hs = run_hashes(d, key)
+    vals = set(hs.values())
+    if not hs or None in vals:
+        why = f"no {key} in its logs (a bench.py older than round 4?)"
+    elif len(vals) != 1:
+        why = f"its runs measured different builds: {hs}"
+    elif vals != {tree_hash}:
+        why = f"measured on kernel sources {vals.pop()}, the tree is {tree_hash}: re-run the profile set on this tree"
+    else:
+        return tree_hash
+    refused.append(wl)
+    print(f"[collect_profiles] REFUSED {wl}: {why}", file=sys.stderr)
+    return None
 
 
 def newest(path, pattern):  # gpurun merges into gpurun_out/ without deleting older runs: keep the newest file per pass
@@ -47,6 +96,10 @@ for wl in sorted(os.listdir(src)) if os.path.isdir(src) else []:
     d = os.path.join(src, wl)
     if not os.path.isdir(d):
         continue
+    is_als = wl.startswith("als")
+    sha = provenance(d, wl, "als_src_sha16" if is_als else "kernel_src_sha16", als_source_hash() if is_als else kernel_source_hash())
+    if sha is None:
+        continue
     blog = os.path.join(d, "bench.log")
     lines = [l for l in open(blog) if l.startswith("{")] if os.path.exists(blog) else []
     if lines:
@@ -77,22 +130,26 @@ for wl in sorted(os.listdir(src)) if os.path.isdir(src) else []:
         # bytes of a wide coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-byte stores.  For the scatter
         # passes a third of the read requests are 8- / 12-byte gathers, for which the half-count is not established:
         # the corrected figure is an UPPER bound there and the raw sum is kept beside it.
+        old = traffic.get(f"{name}@{Z}")
+        if old and old.get("fetch_size_kib_raw") == fetch_kb and old.get("write_size_kib_raw") == write_kb:
+            continue  # the same measurement as recorded: kept as it is (never re-stamped)
         traffic[f"{name}@{Z}"] = {
             "nnz": Z, "rows": int(cfg["rows_per_gpu"]), "cols": int(cfg["cols"]), "workload": wl,
             "fetch_size_kib_raw": fetch_kb, "write_size_kib_raw": write_kb,
             "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024),
             "hbm_bytes_per_launch_uncorrected": int((fetch_kb + write_kb) * 1024),
-            "kernel_src_sha16": kernel_source_hash(), "collected": datetime.date.today().isoformat(),
-            "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE half-count correction"}
+            "kernel_src_sha16": sha, "collected": datetime.date.today().isoformat(),
+            "note": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 FETCH_SIZE half-count correction; hash taken from the measured runs' own bench lines"}
 # ALS: both half-sweeps of one iteration (k_als_gram* kernels; everything else in an iteration is negligible)
 for wl in ("als", "als128"):
     d = os.path.join(src, wl)
     blog = os.path.join(d, "bench.log")
-    if not os.path.exists(blog):
+    if not os.path.exists(blog) or wl in refused:
         continue
     lines = [l for l in open(blog) if l.startswith("{")]
     if not lines:
         continue
+    sha = json.loads(lines[-1]).get("als_src_sha16")
     w = json.loads(lines[-1])["config"]["workload"]  # "<rows>x<cols> nnz=<Z> k=<k>"
     Z, k = int(w.split("nnz=")[1].split()[0]), int(w.split("k=")[1])
     per_kernel = {}
@@ -106,11 +163,16 @@ for wl in ("als", "als128"):
     if len(per_kernel) == 2:
         iters = max(1, len(per_kernel["FETCH_SIZE"]) // 2)  # two half-sweep launches per iteration
         fetch_kb, write_kb = sum(per_kernel["FETCH_SIZE"]) / iters, sum(per_kernel["WRITE_SIZE"]) / iters
+        old = traffic.get(f"als_iteration_k{k}@{Z}")
+        if old and old.get("fetch_size_kib_raw") == fetch_kb and old.get("write_size_kib_raw") == write_kb:
+            continue
         traffic[f"als_iteration_k{k}@{Z}"] = {
             "nnz": Z, "k": k, "fetch_size_kib_raw": fetch_kb, "write_size_kib_raw": write_kb,
             "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024), "hbm_bytes_per_launch_uncorrected": int((fetch_kb + write_kb) * 1024),
-            "kernel_src_sha16": hashlib.sha256(open(os.path.join(ROOT, "cuda-recommender_amd", "csrc", "als_solver.hip"), "rb").read()).hexdigest()[:16],
+            "kernel_src_sha16": sha,
             "collected": datetime.date.today().isoformat(),
             "note": "sum over the two half-sweep kernels of one iteration; 2*FETCH_SIZE + WRITE_SIZE, gfx950 half-count correction (upper bound: most reads are 256-byte row gathers)"}
 json.dump(traffic, open(tpath, "w"), indent=1)
-print(json.dumps({k: (v["hbm_bytes_per_launch"], v["hbm_bytes_per_launch_uncorrected"]) for k, v in traffic.items()}, indent=1))
+print(json.dumps({k: (v["hbm_bytes_per_launch"], v["hbm_bytes_per_launch_uncorrected"], v["kernel_src_sha16"]) for k, v in traffic.items()}, indent=1))
+if refused:
+    sys.exit(2)
