@@ -328,6 +328,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-als", action="store_true", help="skip the ALS leg (configs[3], 3 iterations at k = 64 on the resident matrix; N = 1, default workload only)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1, default workload: skip the config5_strong leg (configs[4] on the same ranks)")
+    ap.add_argument("--force-strong", action="store_true",
+                    help="N = 1 only (rehearsal on a one-GPU box): run the config5_strong leg too, through a 1-rank process group and a 1-rank RCCL communicator")
     ap.add_argument("--strong-steps", type=int, default=2, help="timed outer iterations of the config5_strong leg, per overlap setting")
     ap.add_argument("--no-rank-one", action="store_true",
                     help="skip the standalone rank-one sweep measurement (one extra outer iteration at T = 2, N = 1 only)")
@@ -586,10 +588,19 @@ def main() -> None:
 
     # ---------------- N > 1: the strong-scaling workload of the north star on the same ranks ----------------
     strong = None
-    if world > 1 and a.workload == "netflix" and not a.no_strong:
+    if (world > 1 or a.force_strong) and a.workload == "netflix" and not a.no_strong:
         del d, col_cnt
         torch.cuda.empty_cache()
+        if world == 1:  # --force-strong: the leg's collectives through one-rank groups
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+            if comm is None:
+                comm = mfx.Comm(mfx.Comm.unique_id(), 0, 1, local_rank)
         strong = config5_strong_leg(a, torch, dist, mfx, synth_torch, comm, world, rank, local_rank, dev)
+        if world == 1:
+            comm.close()
+            dist.destroy_process_group()
 
     if rank == 0:
         if strong:

@@ -315,6 +315,18 @@ def test_bench_launches_its_own_workers():
         assert len(lines) == 1, r.stdout
         d = json.loads(lines[0])
         assert d == {"dry_run": True, "n_gpus": n, "rank_sum": want, "workload": "config5"}
+    # (r4) the DEFAULT workload at N > 1 -- what the driver's scaling run launches -- carries the north star's strong-scaling
+    # workload as a second object in the same line: config5_strong, with exactly the keys the real leg fills in
+    sys.path.insert(0, ROOT)
+    import bench
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 8 and tuple(d["config5_strong"].keys()) == bench.CONFIG5_STRONG_KEYS
+    for must in ("ms_per_step", "value", "allreduce_us_per_inner_iter", "host_enqueue_ms_per_step", "rank_nnz_min", "rank_nnz_max", "speedup_vs_n1", "n1_source"):
+        assert must in bench.CONFIG5_STRONG_KEYS
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--no-strong"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "config5_strong" not in json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     # a worker that fails makes the launcher fail
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--no-such-flag"],
                        capture_output=True, text=True, timeout=600, env=env)
@@ -331,3 +343,57 @@ def test_bench_launches_its_own_workers():
         assert f"rank {bad} exited with status 3" in r.stderr
         assert time.time() - t0 < 120
         assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_profile_collector_refuses_foreign_builds(tmp_path):
+    """(r4) tools/collect_profiles.py ties every PMC record to the kernel sources it was MEASURED on: the hash comes from the
+    bench lines inside the run directory's own logs.  A run measured on another build (a foreign hash), or whose runs
+    disagree, is refused -- exit status 2, nothing copied, no traffic entry; a run of this tree is recorded with that hash,
+    and collecting the same run again does not touch the entry (no re-stamping)."""
+    import json
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    tool = os.path.join(ROOT, "tools", "collect_profiles.py")
+    Z, m, n = 1000, 50, 20
+
+    def make_run(root, sha_bench, sha_pmc):
+        d = root / "final" / "netflix"
+        for sub in ("pmc_fetch_size/x", "pmc_write_size/x"):
+            (d / sub).mkdir(parents=True, exist_ok=True)
+        line = lambda sha: json.dumps({"metric": "m", "n_gpus": 1, "kernel_src_sha16": sha, "als_src_sha16": "0" * 16,
+                                       "config": {"rows_per_gpu": m, "cols": n, "nnz_global": Z}}) + "\n"
+        (d / "bench.log").write_text(line(sha_bench))
+        (d / "pmc_fetch_size.log").write_text("rocprof chatter\n" + line(sha_pmc))
+        (d / "pmc_write_size.log").write_text(line(sha_pmc))
+        hdr = "Kernel_Name,Counter_Name,Counter_Value\n"
+        (d / "pmc_fetch_size/x/1_counter_collection.csv").write_text(hdr + '"void mfx::k_flat<2, true>(args)",FETCH_SIZE,100\n"void mfx::k_flat<3, true>(args)",FETCH_SIZE,120\n')
+        (d / "pmc_write_size/x/1_counter_collection.csv").write_text(hdr + '"void mfx::k_flat<2, true>(args)",WRITE_SIZE,50\n"void mfx::k_flat<3, true>(args)",WRITE_SIZE,60\n')
+
+    def collect(root):
+        return subprocess.run([sys.executable, tool, "rXX", "--src", str(root / "final"), "--dst", str(root / "profiles")],
+                              capture_output=True, text=True, timeout=120)
+
+    tree = bench.kernel_source_hash()
+    foreign = tmp_path / "foreign"
+    make_run(foreign, "deadbeefdeadbeef", "deadbeefdeadbeef")
+    r = collect(foreign)
+    assert r.returncode == 2 and "REFUSED netflix" in r.stderr and "deadbeefdeadbeef" in r.stderr
+    assert not (foreign / "profiles" / "rXX_bench_netflix.json").exists()
+    assert json.load(open(foreign / "profiles" / "traffic.json")) == {}
+    mixed = tmp_path / "mixed"
+    make_run(mixed, tree, "deadbeefdeadbeef")  # the bench line is this tree's, the counter passes ran another build
+    r = collect(mixed)
+    assert r.returncode == 2 and "different builds" in r.stderr
+    good = tmp_path / "good"
+    make_run(good, tree, tree)
+    r = collect(good)
+    assert r.returncode == 0, r.stderr
+    t1 = json.load(open(good / "profiles" / "traffic.json"))
+    ent = t1[f"ccd_fused_csc_pass@{Z}"]
+    assert ent["kernel_src_sha16"] == tree and ent["hbm_bytes_per_launch"] == (2 * 100 + 50) * 1024
+    t1[f"ccd_fused_csc_pass@{Z}"]["collected"] = "1999-01-01"  # an old entry of the same measurement ...
+    json.dump(t1, open(good / "profiles" / "traffic.json", "w"))
+    assert collect(good).returncode == 0
+    assert json.load(open(good / "profiles" / "traffic.json"))[f"ccd_fused_csc_pass@{Z}"]["collected"] == "1999-01-01"  # ... is not re-stamped
