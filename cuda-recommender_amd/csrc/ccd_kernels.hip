@@ -248,7 +248,7 @@ __device__ __forceinline__ float2 load_partial_sc1(const float2* p) {
 
 template <int MODE, bool LDS, int BLOCK, bool PSCHK, bool FUSE = false>
 __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
-    static_assert(!FUSE || (LDS && ModeTraits<MODE>::kDot), "fused finalize: LDS-panel passes that produce sums");
+    static_assert(!FUSE || ModeTraits<MODE>::kDot, "fused finalize: passes that produce sums");
     using TR = ModeTraits<MODE>;
     // FUSE: dispatch slot -> chunk through wg_order (ascending first segment, so that the chunks of one segment
     // group run at about the same time and groups complete all along the pass, not at its end)
@@ -304,7 +304,10 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
         for (uint32_t j = threadIdx.x; j < cnt; j += BLOCK) ps_lds[j] = perseg[a.seg_of_rank[win_base + j]];
     }
     if constexpr (LDS) __syncthreads();
-    if constexpr (!FUSE) { if (span >= a.nspans) return; }  // (LDS panels: never true, every chunk holds BLOCK / 64 spans)
+    // a wave without work (plain layout: a span beyond the last one, or one that holds only padding) skips the stream loop;
+    // with the fused finalize it still joins the epilogue's barriers
+    bool live = span < a.nspans;  // (LDS panels: always true, every chunk holds BLOCK / 64 spans)
+    if constexpr (!FUSE) { if (!live) return; }
     auto fetch_ps = [&](uint32_t r) -> P {  // r: rank, always valid where this is called
         if constexpr (LDS) {
             const uint32_t rl = r - win_base;
@@ -316,16 +319,20 @@ __global__ __launch_bounds__(BLOCK) void k_flat(FlatArgs a) {
     uint32_t ntiles = a.tiles_per_span;
     if constexpr (!LDS) {  // plain layout: tiles that start at or beyond nnz hold only padding
         const uint64_t left = a.nnz > start ? a.nnz - start : 0;
-        const uint32_t live = (uint32_t) ((left + kTileElems - 1) / kTileElems);
-        if (live < ntiles) ntiles = live;
-        if (ntiles == 0) {  // nothing stored here (plain layout, nnz == 0): still own the carry slot
-            if (TR::kDot && lane == 0) a.carry[span] = make_float2(0.f, 0.f);
-            return;
+        const uint32_t nlive = (uint32_t) ((left + kTileElems - 1) / kTileElems);
+        if (nlive < ntiles) ntiles = nlive;
+        if (live && ntiles == 0) {  // nothing stored here (plain layout, nnz == 0): still own the carry slot
+            if (TR::kDot && lane == 0) store_partial<FUSE>(a.carry + span, 0.f, 0.f);
+            live = false;
         }
-        id_n = __builtin_nontemporal_load(idx4);
-        v_n = __builtin_nontemporal_load(val4);
-        fl_n = flw[0]; hp_n = hpw[0]; hp_nn = hpw[8];
+        if constexpr (!FUSE) { if (!live) return; }
+        if (live) {
+            id_n = __builtin_nontemporal_load(idx4);
+            v_n = __builtin_nontemporal_load(val4);
+            fl_n = flw[0]; hp_n = hpw[0]; hp_nn = hpw[8];
+        }
     }
+    if (live) {
     const uint32_t rank_base = __builtin_amdgcn_readfirstlane(hp_n);  // heads before this span
     uint32_t cur1 = rank_base;  // (rank of the segment open at the current position) + 1, wave-uniform
     P pcur{};
@@ -470,6 +477,7 @@ __builtin_nontemporal_store(f32x4{vo[0], vo[1], vo[2], vo[3]}, val4 + tile * 64)
             }
         }
     }
+    }  // live
     if constexpr (FUSE) fused_finalize<BLOCK>(a, chunk, lds_raw);
 }
 
@@ -875,7 +883,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_seg_range(uint32_t nchunks, ui
     if (w >= nchunks) return;
     const uint64_t lo = (uint64_t) w * chunk_len;
     uint64_t hi = lo + chunk_len;
-    const uint32_t pe = panel_end[wg_panel[w]];
+    const uint32_t pe = panel_end[wg_panel ? wg_panel[w] : 0u];  // (plain layout: one panel)
     if (hi > pe) hi = pe;
     if (hi <= lo) { seg_first[w] = 0xFFFFFFFFu; seg_last[w] = 0; return; }
     auto holder = [&](uint32_t q) {  // last v in [0, nv) with ptr_v[v] <= q
@@ -965,10 +973,14 @@ static FlatArgs flat_args_of(const SegStreamDev& s, const void* gather, const vo
 }
 
 static int panel_lanes(const SegStreamDev& s);
-uint32_t fused_group_size(uint32_t npanels) { return 1024u / (npanels >= 8 ? 16u : npanels >= 2 ? 4u : 1u); }
+uint32_t fused_group_size(uint32_t npanels, uint32_t block) { return block / (npanels >= 8 ? 16u : npanels >= 2 ? 4u : 1u); }
 
 template <int MODE>
 int launch_flat_fused_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t st) {
+    if (!s.panel_rows) {  // plain layout: 256-thread workgroups of four spans, no slice; the LDS is the epilogue's scratch only
+        const size_t epilogue = 2 * kBlock * sizeof(float) + ((size_t) s.fz_max_chunk_groups + 2) * sizeof(uint32_t);
+        return launch_flat_t<MODE, false, kBlock, false, true>(a, (s.nspans + (kBlock / 64) - 1) / (kBlock / 64), epilogue, st);
+    }
     size_t lds_bytes = (((size_t) s.panel_rows + 1) * sizeof(typename ModeTraits<MODE>::S) + 15) / 16 * 16 + (size_t) kPerSegLdsCap * sizeof(typename ModeTraits<MODE>::P);
     const size_t epilogue = 2 * 1024 * sizeof(float) + ((size_t) s.fz_max_chunk_groups + 2) * sizeof(uint32_t);
     if (lds_bytes < epilogue) lds_bytes = epilogue;
@@ -978,15 +990,19 @@ int launch_flat_fused_mode(const SegStreamDev& s, const FlatArgs& a, hipStream_t
 }
 
 int launch_flat_fused(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, const FinalizeArgs& f, hipStream_t st) {
-    MFX_REQUIRE(s.lds_panels && s.spans_per_wg == 16 && s.fz_order && s.fz_g0 && s.fz_g1 && s.fz_expected && s.fz_arrived,
+    MFX_REQUIRE(((s.lds_panels && s.spans_per_wg == 16) || !s.panel_rows) && s.fz_order && s.fz_g0 && s.fz_g1 && s.fz_expected && s.fz_arrived,
                 "launch_flat_fused: the layout carries no fused-finalize tables");
-    MFX_REQUIRE(!f.gh_dense && !f.cnt_override && !f.pack4_as3, "launch_flat_fused: dense / overridden finalize inputs are not fused");
-    MFX_REQUIRE(mode == FM_FCSC || mode == FM_FCSR, "launch_flat_fused: bad mode %d", (int) mode);
+    MFX_REQUIRE(!f.gh_dense && !f.cnt_override && !f.pack4_as3 && !f.nmf && !f.fundec_seg, "launch_flat_fused: dense / overridden / extended finalize inputs are not fused");
+    MFX_REQUIRE(mode == FM_FCSC || mode == FM_FCSR || mode == FM_SWEEP, "launch_flat_fused: bad mode %d", (int) mode);
     FlatArgs a = flat_args_of(s, gather, perseg, 0);
     a.wg_order = s.fz_order; a.wg_g0 = s.fz_g0; a.wg_g1 = s.fz_g1; a.expected = s.fz_expected; a.arrived = s.fz_arrived;
     a.orphans = s.fz_orphans; a.norphans = s.fz_norphans; a.ngroups = s.fz_ngroups; a.panel_lanes = (uint32_t) panel_lanes(s);
     a.nseg = s.nseg; a.npanels = s.npanels; a.ptr_v = s.ptr_v; a.rank_code = s.rank_code; a.seg_cnt = s.seg_cnt;
     a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
+    if (mode == FM_SWEEP) {
+        MFX_REQUIRE(!s.panel_rows, "launch_flat_fused: the fused read-only sweep exists for the plain layout only");
+        return launch_flat_fused_mode<FM_SWEEP>(s, a, st);
+    }
     return mode == FM_FCSC ? launch_flat_fused_mode<FM_FCSC>(s, a, st) : launch_flat_fused_mode<FM_FCSR>(s, a, st);
 }
 
@@ -1002,11 +1018,11 @@ int launch_flat(FlatMode mode, const SegStreamDev& s, const void* gather, const 
     }
 }
 
-int launch_chunk_seg_range(const SegStreamDev& s, const uint32_t* panel_end, uint32_t* seg_first, uint32_t* seg_last, hipStream_t st) {
-    const uint32_t nchunks = s.nspans / s.spans_per_wg;
+int launch_chunk_seg_range(const SegStreamDev& s, uint32_t wg_spans, const uint32_t* panel_end, uint32_t* seg_first, uint32_t* seg_last, hipStream_t st) {
+    const uint32_t nchunks = (s.nspans + wg_spans - 1) / wg_spans;
     if (nchunks == 0) return MFX_OK;
     hipLaunchKernelGGL(k_chunk_seg_range, dim3((nchunks + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nchunks,
-                       (uint64_t) s.tiles_per_span * kTileElems * s.spans_per_wg, s.ptr_v, (size_t) s.npanels * s.nseg, s.nseg, s.wg_panel,
+                       (uint64_t) s.tiles_per_span * kTileElems * wg_spans, s.ptr_v, (size_t) s.npanels * s.nseg, s.nseg, s.panel_rows ? s.wg_panel : nullptr,
                        panel_end, seg_first, seg_last);
     MFX_LAUNCH_CHECK();
     return MFX_OK;

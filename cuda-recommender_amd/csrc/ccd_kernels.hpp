@@ -146,12 +146,13 @@ int launch_test_resid_init(int64_t nnz_test, const uint32_t* row, const uint32_t
 int launch_test_r1(int64_t nnz_test, const uint32_t* row, const uint32_t* col, float* resid, const float* Wt, const float* Ht,
                    const float* oldWt, const float* oldHt, double* block_partials, uint32_t nblocks, double* sum_out, hipStream_t st);
 // segments per group of the fused finalize = 1024 / panel lanes of the finalize (a function of the panel count)
-uint32_t fused_group_size(uint32_t npanels);
+uint32_t fused_group_size(uint32_t npanels, uint32_t block);
 // FM_FCSC / FM_FCSR pass + the finalize of its sums inside the same launch (s.fz_* must be set; f.gh_dense and
 // f.cnt_override are not supported: sharded column sums go through the all-reduce and the separate kernel)
 int launch_flat_fused(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, const FinalizeArgs& f, hipStream_t st);
 // first / last segment of every workgroup chunk's real entries (0xFFFFFFFF / 0 for a chunk of padding only)
-int launch_chunk_seg_range(const SegStreamDev& s, const uint32_t* panel_end, uint32_t* seg_first, uint32_t* seg_last, hipStream_t st);
+// wg_spans: spans per workgroup chunk (16 for LDS panels, 4 for the plain layout's 256-thread workgroups)
+int launch_chunk_seg_range(const SegStreamDev& s, uint32_t wg_spans, const uint32_t* panel_end, uint32_t* seg_first, uint32_t* seg_last, hipStream_t st);
 
 // out[perm[e]] = val[e] for every stored, non-padding element: residual back in input order.
 int launch_unpermute(const SegStreamDev& s, float* out, hipStream_t st);

@@ -59,22 +59,27 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
 // the dispatch order (ascending first segment).  One small kernel finds every chunk's first / last segment; the
 // rest is host arithmetic over a few thousand chunks.
 int SegStreamStore::build_fuse_tables(hipStream_t st) {
-    if (!view.lds_panels || view.spans_per_wg != 16 || view.scatter || view.nseg == 0 || view.nspans == 0) return MFX_OK;
-    const uint32_t nchunks = view.nspans / view.spans_per_wg;
-    if (panel_end_dev_.size() == 0) {
-        const std::vector<uint32_t>& pe = built_on_device_ ? panel_end_host_ : layout_.panel_real_end;
+    // LDS panels with 16-span workgroups (1024 threads), or (r4) the plain layout: 256-thread workgroups of four spans
+    const bool plain = view.panel_rows == 0;
+    if (!(plain || (view.lds_panels && view.spans_per_wg == 16)) || view.scatter || view.nseg == 0 || view.nspans == 0 || !view.ptr_v || !view.rank_code) return MFX_OK;
+    const uint32_t wg_spans = plain ? 4u : 16u, block = plain ? 256u : 1024u;
+    const uint32_t nchunks = (view.nspans + wg_spans - 1) / wg_spans;
+    if (panel_end_dev_.size() == 0 || plain) {
+        std::vector<uint32_t> one{(uint32_t) view.nnz};
+        const std::vector<uint32_t>& pe = plain ? one : built_on_device_ ? panel_end_host_ : layout_.panel_real_end;
         if (pe.size() != view.npanels) return MFX_OK;  // no panel ends at hand: the separate finalize kernel stays
         MFX_TRY(panel_end_dev_.alloc(pe.size()));
         MFX_TRY(panel_end_dev_.upload(pe.data(), pe.size(), MFX_HOST, st));
+        MFX_HIP(hipStreamSynchronize(st));
     }
     DevBuf<uint32_t> d_first, d_last;
     MFX_TRY(d_first.alloc(nchunks)); MFX_TRY(d_last.alloc(nchunks));
-    MFX_TRY(launch_chunk_seg_range(view, panel_end_dev_.get(), d_first.get(), d_last.get(), st));
+    MFX_TRY(launch_chunk_seg_range(view, wg_spans, panel_end_dev_.get(), d_first.get(), d_last.get(), st));
     std::vector<uint32_t> first(nchunks), last(nchunks);
     MFX_HIP(hipMemcpyAsync(first.data(), d_first.get(), sizeof(uint32_t) * nchunks, hipMemcpyDeviceToHost, st));
     MFX_HIP(hipMemcpyAsync(last.data(), d_last.get(), sizeof(uint32_t) * nchunks, hipMemcpyDeviceToHost, st));
     MFX_HIP(hipStreamSynchronize(st));
-    const uint32_t gs = fused_group_size(view.npanels), ngroups = (view.nseg + gs - 1) / gs;
+    const uint32_t gs = fused_group_size(view.npanels, block), ngroups = (view.nseg + gs - 1) / gs;
     std::vector<uint32_t> g0(nchunks), g1(nchunks), expected(ngroups, 0u), order(nchunks), orphans;
     uint32_t max_groups = 0;
     for (uint32_t w = 0; w < nchunks; ++w) {
@@ -627,7 +632,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     for (hipEvent_t& e : ev_) MFX_HIP(hipEventCreate(&e));
     m_ = (uint32_t) R->rows; n_ = (uint32_t) R->cols; k_ = p->k; nnz_ = (uint64_t) R->nnz;
     prof_.enable(p->profile != 0 || p->schedule == 0);
-    if (const char* e = std::getenv("MFX_FUSE_FINALIZE")) fuse_finalize_ = std::atoi(e) != 0;  // opt-in: see fuse_finalize_
+    if (const char* e = std::getenv("MFX_FUSE_FINALIZE")) fuse_finalize_ = std::atoi(e) != 0 ? 1 : 0;  // opt-in: see fuse_finalize_
 
     // Layouts.  Hyper-sparse shapes (LDS-sized panels would leave < 8 entries per (panel, segment) pair on
     // either side, so that side would fall back to L2 "cache panels") take the scatter layout on BOTH sides
@@ -1001,7 +1006,7 @@ int CcdSolver::rank_fused(uint32_t t) {
     FinalizeArgs fv = fin_base();
     fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next);
     fv.pack4 = packC_.get();
-    if (fuse_finalize_ && !ext_on_ && !comm_ && csc_.can_fuse_finalize()) {
+    if (use_fused(csc_) && !comm_) {
         PROF(KernelProfiler::K_FCSC, launch_flat_fused(FM_FCSC, csc_.view, packA_.get(), packB_.get(), fv, st_));
     } else {
         PROF(KernelProfiler::K_FCSC, launch_flat(FM_FCSC, csc_.view, packA_.get(), packB_.get(), 0, st_));
@@ -1010,7 +1015,7 @@ int CcdSolver::rank_fused(uint32_t t) {
     // per-row scalars of the CSR pass are exactly packA (u_prev_new, u_t_old), indexed by row
     FinalizeArgs fu = fin_base();
     fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
-    if (fuse_finalize_ && !ext_on_ && csr_.can_fuse_finalize()) {
+    if (use_fused(csr_)) {
         PROF(KernelProfiler::K_FCSR, launch_flat_fused(FM_FCSR, csr_.view, packC_.get(), packA_.get(), fu, st_));
     } else {
         PROF(KernelProfiler::K_FCSR, launch_flat(FM_FCSR, csr_.view, packC_.get(), packA_.get(), 0, st_));
@@ -1020,12 +1025,20 @@ int CcdSolver::rank_fused(uint32_t t) {
     bool stop = false;
     MFX_TRY(inner_stop(t, 1, &stop));
     for (int it = 2; it <= p_.maxinneriter && !stop; ++it) {  // remaining inner iterations: read-only sweeps
-        PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csc_.view, Wt(t), nullptr, 0, st_));
         FinalizeArgs f2 = fin_base(); f2.out_vec = Ht(t);
-        MFX_TRY(finalize_cols(f2));
-        PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csr_.view, Ht(t), nullptr, 0, st_));
+        if (use_fused(csc_) && !comm_ && csc_.view.panel_rows == 0) {
+            PROF(KernelProfiler::K_SWEEP, launch_flat_fused(FM_SWEEP, csc_.view, Wt(t), nullptr, f2, st_));
+        } else {
+            PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csc_.view, Wt(t), nullptr, 0, st_));
+            MFX_TRY(finalize_cols(f2));
+        }
         FinalizeArgs f3 = fin_base(); f3.out_vec = Wt(t);
-        PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, f3, st_));
+        if (use_fused(csr_) && csr_.view.panel_rows == 0) {
+            PROF(KernelProfiler::K_SWEEP, launch_flat_fused(FM_SWEEP, csr_.view, Ht(t), nullptr, f3, st_));
+        } else {
+            PROF(KernelProfiler::K_SWEEP, launch_flat(FM_SWEEP, csr_.view, Ht(t), nullptr, 0, st_));
+            PROF(KernelProfiler::K_FINALIZE, launch_finalize(csr_.view, f3, st_));
+        }
         MFX_TRY(inner_stop(t, it, &stop));
     }
     if (p_.maxinneriter > 1) {  // the packs must carry the FINAL (u_t, v_t)

@@ -124,7 +124,14 @@ private:
     hipEvent_t ev_rank_[2] = {nullptr, nullptr};
     std::vector<double> trace_rmse_, trace_secs_;
     std::vector<int32_t> trace_done_;
-    bool fuse_finalize_ = false;  // MFX_FUSE_FINALIZE=1 / 2: finalize inside the fused passes (bit-identical; measured slower)
+    // finalize inside the fused passes ("last workgroup to arrive finalizes", bit-identical to the separate kernel): OPT-IN,
+    // MFX_FUSE_FINALIZE=1 / 2 -- it measured slower than a kernel boundary on LDS panels (r2, ccd_kernels.hip) AND, generalised
+    // to the plain layout of small matrices in r4 (one graph node per pass instead of two), there as well: ML-1M shape k = 40
+    // under hipGraph replay 0.786 ms per outer iteration with 160 nodes of ~4.9 us, 1.115 ms with 80 fused nodes of ~13.9 us
+    // (drain of the write-through partials, one returning agent-scope atomic, then the completing workgroup's chain of
+    // dependent past-the-cache loads: ~9 us of tail against a ~5 us node boundary; profiles/r04_exp_small.txt).
+    int fuse_finalize_ = 0;
+    bool use_fused(const SegStreamStore& s) const { return fuse_finalize_ == 1 && !ext_on_ && s.can_fuse_finalize(); }
     int rank_fused(uint32_t t);
     int rank_as_written(uint32_t t, bool add_back);
     int flush_pending();

@@ -397,14 +397,16 @@ def test_failing_shard_does_not_strand_the_others(mfx, medium):
     assert res[2] == "aborted" and all(isinstance(x, str) and x.startswith("error") and "aborted" in x for x in res[:2]), res
 
 
-@pytest.mark.parametrize("panel_rows,tiles,T", [(64, 0, 1), (97, 2, 1), (4096, 0, 2), (300, 4, 1)])
+@pytest.mark.parametrize("panel_rows,tiles,T", [(64, 0, 1), (97, 2, 1), (4096, 0, 2), (300, 4, 1), (-1, 0, 1), (-1, 2, 3), (0, 4, 2)])
 def test_fused_finalize_equals_the_separate_kernel(mfx, medium, monkeypatch, panel_rows, tiles, T):
     """Opt-in (MFX_FUSE_FINALIZE=1, =2 with the dispatch sorted by first segment; off by default because it measured
     slower): the finalize of a fused pass runs inside the pass (the workgroup whose arrival completes a group of segments
     computes g / (lambda |Omega| + h) for it, reading the other workgroups' partial sums past the caches):
     same lookups and order of additions as k_finalize, so factors, RMSE trace and residuals are bit-identical to
     a solve with MFX_FUSE_FINALIZE=0 -- on layouts with many panels and short spans (many chunks per group,
-    segments crossing chunks) and over several outer iterations (the arrival counters reset themselves)."""
+    segments crossing chunks) and over several outer iterations (the arrival counters reset themselves).
+    (r4) Also the PLAIN layout (panel_rows -1, or 0 = chosen for this small matrix), where it is the default: 256-thread
+    workgroups of four spans, the read-only sweeps of T > 1 fused as well."""
     d = medium
     k, lam, t = 6, 0.05, 4
     W0 = mfx.initial_col(k, d.rows)
@@ -422,6 +424,34 @@ def test_fused_finalize_equals_the_separate_kernel(mfx, medium, monkeypatch, pan
         for a, b in zip(o[:4], outs[2][:4]):
             assert np.array_equal(bits(a), bits(b))
         assert np.array_equal(o[4], outs[2][4])
+
+
+def test_plain_layout_can_fuse_the_finalize(mfx, medium, monkeypatch):
+    """(r4) The fused finalize also exists for the plain layout of small matrices (256-thread workgroups of four spans; the
+    read-only sweeps of T > 1 too): with MFX_FUSE_FINALIZE=1 every pass carries its finalize -- two launches per rank instead
+    of four.  Opt-in, because under hipGraph replay it measured slower than the kernel boundary it removes (ccd_solver.hpp)."""
+    d, k = medium, 5
+
+    def launches(panel_rows, T=1):
+        p = _params(mfx, k, 0.05, 1, T, 1, 1, 0, panel_rows)
+        p.profile = 1
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), p)
+        s.set_factors(mfx.initial_col(k, d.rows))
+        s.iterate(1)
+        kt = s.kernel_times()
+        info = s.layout_info()
+        s.close()
+        return {n: v[1] for n, v in kt.items()}, info
+
+    monkeypatch.delenv("MFX_FUSE_FINALIZE", raising=False)
+    kt, info = launches(0)
+    assert info["csc"]["kind"] == "plain" and info["csr"]["kind"] == "plain", info
+    assert kt["ccd_finalize"] == 2 * k, kt
+    monkeypatch.setenv("MFX_FUSE_FINALIZE", "1")
+    kt, _ = launches(0)
+    assert kt.get("ccd_finalize", 0) == 0 and kt["ccd_fused_csc_pass"] == k and kt["ccd_fused_csr_pass"] == k, kt
+    kt, _ = launches(0, T=3)
+    assert kt.get("ccd_finalize", 0) == 0 and kt["ccd_flat_sweep"] == 4 * k, kt
 
 
 # ---- the flags the reference parses and ignores (-N, -e, -p/-q), opt-in with their LIBPMF meaning ---------------------
