@@ -268,6 +268,9 @@ struct OpCtx {
 }  // namespace
 
 // variant -> layout of the single-operator entry points (see mfx.h)
+// variants of the single-operator entry points: -1 reference order / 0 wave per segment (plain layout), 1 flat (plain),
+// 2 flat with the layout chosen for the shape, >= 16 explicit LDS panel, <= -16 explicit cache panel.  Anything else is an error.
+static bool op_variant_ok(int variant) { return variant == -1 || variant == 0 || variant == 1 || variant == 2 || variant >= 16 || variant <= -16; }
 static FlatLayoutOptions op_layout(int variant, int64_t nseg, int64_t nnz, int64_t vec_len) {
     mfx_params p;
     mfx_params_default(&p);
@@ -282,6 +285,7 @@ int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uin
         MFX_REQUIRE(nnz == 0 || (idx && val), "mfx_rank_one_sweep: null idx / val with nnz > 0");
         MFX_REQUIRE(nseg < (int64_t) 0xFFFFFFFFll && vec_len < (int64_t) 0xFFFFFFFFll && nnz < (int64_t) 0xFFFF0000ll,
                     "mfx_rank_one_sweep: sizes exceed the 32-bit index range");
+        MFX_REQUIRE(op_variant_ok(variant), "mfx_rank_one_sweep: variant must be -1, 0, 1, 2, >= 16 or <= -16 (got %d)", variant);
         OpCtx cx;
         MFX_TRY(cx.open(device));
         SegStreamStore s;
@@ -323,6 +327,7 @@ int mfx_update_rating(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint
         MFX_REQUIRE(nnz == 0 || (idx && val), "mfx_update_rating: null idx / val with nnz > 0");
         MFX_REQUIRE(nseg < (int64_t) 0xFFFFFFFFll && vec_len < (int64_t) 0xFFFFFFFFll && nnz < (int64_t) 0xFFFF0000ll,
                     "mfx_update_rating: sizes exceed the 32-bit index range");
+        MFX_REQUIRE(op_variant_ok(variant), "mfx_update_rating: variant must be -1, 0, 1, 2, >= 16 or <= -16 (got %d)", variant);
         OpCtx cx;
         MFX_TRY(cx.open(device));
         SegStreamStore s;
@@ -331,7 +336,9 @@ int mfx_update_rating(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uint
         DevBuf<float> dg, dp;
         MFX_TRY(dg.alloc(vec_len)); MFX_TRY(dg.upload(gathered, vec_len, MFX_HOST, cx.st));
         MFX_TRY(dp.alloc(nseg)); MFX_TRY(dp.upload(per_seg, nseg, MFX_HOST, cx.st));
-        if (variant <= 0 && variant > -16) MFX_TRY(launch_resid_wave(s.view, dg.get(), dp.get(), add, cx.st));
+        // 0: one wavefront per segment; -1 takes the flat kernel over its plain layout, like CcdSolver::resid (the update is
+        // elementwise -- bit-identical in every kernel)
+        if (variant == 0) MFX_TRY(launch_resid_wave(s.view, dg.get(), dp.get(), add, cx.st));
         else MFX_TRY(launch_flat(FM_RESID, s.view, dg.get(), dp.get(), add, cx.st));
         if (nnz) {
             DevBuf<float> tmp;

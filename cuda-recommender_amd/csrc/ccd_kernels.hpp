@@ -61,6 +61,7 @@ struct SegStreamDev {
     uint32_t scat_grp_lo[kMaxScatterGroups + 1] = {};    // first local index (of the gathered dimension) of group j; [ngroups] = gather_len
     const uint32_t* slab_lo = nullptr;         // [npanels + 1] first slab of every panel (a panel's slabs are consecutive)
     uint32_t* scat_slab_bad = nullptr;         // [slabs] a term of the slab was not representable in the fixed-point sums
+    uint32_t scat_max_local_cnt = 0;           // most stored entries any index of the gathered (local) dimension has: bounds a fixed-point sum (0: unknown, treated as 1)
     // fused finalize (LDS panels, 16-span workgroups): see fused_finalize in ccd_kernels.hip; nullptr = not available
     const uint32_t* fz_order = nullptr;        // [workgroups] dispatch slot -> chunk
     const uint32_t* fz_g0 = nullptr;           // [workgroups] first / last segment group of a chunk

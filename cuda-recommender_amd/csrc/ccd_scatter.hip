@@ -1,62 +1,55 @@
 // ccd_scatter.hip -- CCD++ passes for HYPER-SPARSE orientations (config 5's shard: 1.25 M x 1 M with
-// 125 M ratings, ~100 entries per row / column, density 1e-4).
+// 125 M ratings, ~100 entries per row / column, density 1e-4).  Measured numbers and their history: DESIGN.md section 4.2.
 //
 // Why another kernel.  The flat-stream kernel (ccd_kernels.hip) reduces per segment and gathers the
 // other operand; its gather is served from LDS only if the gathered dimension is cut into LDS-sized
 // panels, and at this density a (panel, segment) pair holds 0.6 entries: the segments are shredded.
 // Round 1 therefore fell back to L2-sized "cache panels" with per-lane global gathers, which the
-// texture path serves at ~85 G gathers/s -- 0.2 of the HBM roofline (profiles/r02_ubench_scatter.txt,
-// "RANDOM global row operand": 1.5 ms per 126 M entries).
+// texture path serves at ~85 G gathers/s -- 0.2 of the HBM roofline (profiles/r02_ubench_scatter.txt).
 //
 // What this kernel does instead: SWAP THE ROLES.  A pass that needs the sums over COLUMNS streams the
 // ROW-major copy (and vice versa), stored panel-major over the columns:
 //   * the panel's columns are local (16-bit index): their operands AND their (g, h) accumulators sit in
-//     LDS (24 B per column, 6816 columns per workgroup: all of a CU's 160 KB);
+//     LDS (24 B per column, up to 6816 columns per workgroup: all of a CU's 160 KB);
 //   * inside a panel the entries keep the copy's row-major order, so the row operand is an ASCENDING,
 //     nearly sequential global read (a wave's 256 entries span ~400 rows = ~25 cache lines instead of
-//     256 random ones) -- the row id of every entry is stored explicitly (4 B/nnz: 14 B/nnz streamed);
+//     256 random ones); the row id of an entry is one byte -- its step from the previous entry of the tile's
+//     sorted order -- plus one base per tile (11 B per non-zero streamed; explicit 32-bit ids, 14 B, where a step overflows);
 //   * the reduction is a scatter-add into the LDS accumulators.  It is made ORDER-INDEPENDENT, hence
 //     bitwise reproducible, by accumulating the fp32 contributions in 64-bit fixed point (ds_add_u64,
-//     scale 2^36: exact for |x| < 1.3e8, resolution 1.5e-11; an fp32 sum of n such terms is off by
+//     scale 2^36: exact for |sum| < 1.3e8, resolution 1.5e-11; an fp32 sum of n such terms is off by
 //     ~6e-8 * |sum| * sqrt(n), the fixed-point one by ~1e-11 * sqrt(n)).  LDS fp32 atomics would be both
-//     non-deterministic and 4x slower (same profile: 1.39 ms vs 0.34 ms).
+//     non-deterministic and 4x slower (profiles/r02_ubench_ldsatomic.txt).
 // A workgroup flushes its accumulators to a slab when it leaves a panel; k_scatter_combine adds the slabs of a
 // panel (integers: any order gives the same bits) and converts to the dense fp32 (g, h) that the ordinary
 // finalize / all-reduce path takes.
 //
-// (r3) PERSISTENT WORKGROUPS.  The grid is one workgroup per CU (the LDS allows no more); workgroup w owns the
-// contiguous chunk range [chunk_lo[w], chunk_lo[w+1]) of the panel-major stream and keeps a panel's slice and
-// accumulators in LDS across all of its chunks of that panel -- it reloads / flushes only where the panel changes
-// inside its range.  Round 2 launched one workgroup per 57 k-entry chunk: 2180 of them on the shard, each loading a
-// 54 KB slice, zeroing 109 KB of LDS, writing a 107 KB slab (read again by the combine) and -- alone on its CU --
-// leaving the CU idle through its own prologue and epilogue.  Now ~256 + npanels slabs instead of 2180 (the slabs
-// of a panel are still consecutive: ranges and panels are both ascending), and a wave's tile pipeline runs on
-// across chunk boundaries.  Measured on the shard (profiles/r03_sweep_shard_persistent.txt): column-sum pass 454 ->
-// 365 us (0.53 of the roofline), row-sum pass 476 -> 462 us (0.42), combine 39 -> 12 us, outer iteration at k = 128
-// 132 -> 111 ms; and the span length no longer matters (2 ... 14 tiles: 111-115 ms; round 2's 444-713 us scatter over
-// 8 ... 32 tiles was the per-chunk prologue / epilogue, whose weight changed with the chunk size).
-// What bounds a pass now is the CU's read path from L2: rocprofv3 counts 42 (column sums) / 54 (row sums) 128-byte
-// TCP -> TCC read requests per 256-entry tile (profiles/r03_pmc_scatter*.txt), and both passes run at one request
-// per ~10.7 clocks per CU -- the same ~12 B/clk/CU the flat pass streams at.  14 of those lines are the streams
-// (7 B per entry); the other 28 / 40 are the streamed operand: at 0.68 entries per (panel, id) pair every line of the
-// operand is fetched once per panel and half of its entries are used (8-byte pairs: 2 KB useful of 3.6 KB; 12-byte
-// triples in the row-sum pass: 3 KB of 5.1 KB).  Tried on the persistent kernel and dropped (no change beyond
-// noise): de-phasing the 16 waves of a workgroup with a per-wave start delay (the units are not used in bursts), and
-// an XCD-major range order in which each XCD owns a contiguous eighth of the panels (L2 hits on the operand do not
-// relieve the CU's request path -- same finding as in round 2).
+// (r3) PERSISTENT WORKGROUPS.  The grid is one workgroup per CU (the LDS allows no more); workgroup w owns a
+// contiguous chunk range of the panel-major stream and keeps a panel's slice and accumulators in LDS across all of
+// its chunks of that panel -- it reloads / flushes only where the panel changes inside its range (~256 + npanels slabs
+// per pass instead of one per 57 k-entry chunk), and a wave's tile pipeline runs on across chunk boundaries.
 //
-// Measured on the shard shape (k = 128): 0.51 ms (column sums, 8-byte streamed operand) / 0.66 ms (row sums,
-// 16-byte operand) per pass against 0.85 / 0.93 ms for cache panels; 244 -> 160 ms per outer iteration.  What
-// bounds it now is the vector-memory path of the CU (~10 B/clk/CU whether a load is served by HBM, the Infinity
-// Cache or L2): per non-zero 10 B of streams + 4 B stored + the L1 line fills of the streamed operand, which at
-// 0.6 entries per (panel, row) pair cost as much as the streams themselves (npanels x |operand| = 1.6 / 3.3 GB per
-// pass).  Tried and dropped, all measured on that shape: a deeper software pipeline (gathers a tile ahead, three
-// register sets: 0.52 / 0.67 ms -- latency is not the bound); an XCD-aware workgroup order that keeps every XCD's
-// slice of the operand in its L2 across panels (workgroup b does land on XCD b % 8, tools/ubench_xcd.hip, but the
-// passes slowed to 0.62 / 0.74 ms: L2 hits do not relieve the path); the natural order inside a tile (every
-// gather instruction then touches all ~26 lines of the tile's row window and 16 waves' windows do not fit the
-// 32 KB L1: 0.55-0.65 / 0.75-0.82 ms).  The first microbenchmark (profiles/r02_ubench_scatter.txt, 0.40 ms) used
-// a denser synthetic gap pattern than the real layout; on the real layout it measures 0.49 ms.
+// (r4) WHAT BOUNDED THE PASS, AND THE FIX.  Round 3 read its counters as "the CU's read path from L2, one 128-byte request
+// per ~10.8 clocks".  The same counters say more: TCC_MISS equalled ALL reads -- every line of the streamed operand, which
+// each panel re-reads in full (npanels x 10-12 MB per pass), missed the L2 and came through the fabric, and streams plus
+// operand together moved ~6.2-6.7 TB/s of L2-miss traffic: the pass was bound by the memory side, on bytes it did not
+// need to fetch from there.  The operand missed because the 256 persistent workgroups were at 256 different PHASES of
+// their panels (range length = 0.57 / 0.72 panel), so at any moment the chip read 256 places spread over the whole
+// operand.  With EQUAL panels and a panel count that is a multiple of (workgroups / 8) -- the layout rule in
+// CcdSolver::build_stores -- the phase of workgroup w depends on w mod 8 only, which is also its XCD: every XCD's
+// workgroups walk the operand in step, one window of it is live per L2, and the re-reads are L2 hits (TCC_MISS 23.1 M ->
+// 12.6 M per row-sum pass = the streams alone).  Config-5 shard: column-sum pass 358 -> 307 us, row-sum pass 448 -> 354 us
+// (profiles/r04_exp_scatter_alignment.txt).  What is left, from knock-out builds in the same file: the streams alone
+// (gathers served from L1) take 236-268 us = 5.2-5.8 TB/s of the 11 B per non-zero; the operand now costs its bytes at
+// ~18 TB/s, the guide's L2-served rate, ON TOP (+48 us for 1.6 GB of pairs, +129 us for 2.3 GB of 12-byte triples; a
+// float4 operand: +167 us) -- the L2 -> L1 fills and the HBM streams share the CU's one vector-memory path and add.
+// Neither the LDS atomics (knocked out: -2 %), nor the fixed-point conversion (-1 %), nor latency (streams three tiles
+// ahead, gathers one: +-0) bound it.
+//
+// (r4) PANEL GROUPS.  A store can be launched group by group (consecutive panels each; SegStreamDev::scat_ngroups), each
+// launch aligned on its own, so that in a sharded solve group j's sums are combined, all-reduced and finalized on a
+// second stream while group j + 1 is streamed (CcdSolver::rank_fused_scatter).  The sums are integers: any grouping
+// gives the same bits (test_scatter_overlap_groups_are_bit_identical).
 //
 // The per-element arithmetic is the reference's (unfused multiply, subtract, multiply, add) as in the flat
 // kernel, so both residual copies keep holding bit-identical values whichever kernel updates them.
@@ -88,8 +81,8 @@ __device__ __forceinline__ float sub_rn(float a, float b) {
     return a - b;
 }
 
-// fp32 -> 64-bit fixed point (two's complement), scale 2^36: |x| must stay below 2^27 (kFixedLimit; checked per
-// term, see `bad`), resolution 2^-36 (terms are truncated toward zero at that resolution; an fp32 with |x| >= 2^-12
+// fp32 -> 64-bit fixed point (two's complement), scale 2^36: every SUM must stay below 2^27 (kFixedLimit; enforced per
+// term against kFixedLimit / (entries of the fullest local index), see `bad` and ScatterArgs::term_limit), resolution 2^-36 (terms are truncated toward zero at that resolution; an fp32 with |x| >= 2^-12
 // converts exactly).
 // (r2: a 3-instruction conversion -- fma onto 1.5 * 2^52, integer in the low mantissa bits -- instead of this
 // 9-instruction f64 -> i64 sequence changed nothing: 339 vs 345 us on the Netflix shape, 531 vs 510 us on the
@@ -114,6 +107,7 @@ struct ScatterArgs {
     const uint32_t* chunk_lo; // [workgroups + 1] chunk range of every persistent workgroup
     const uint32_t* slab0;    // [workgroups] first slab a workgroup writes (one per panel it visits, ascending)
     uint32_t* slab_bad;       // [slabs] != 0: some term of the slab was NaN / Inf / beyond the fixed-point range
+    float term_limit;         // a term must stay below this: kFixedLimit / (most entries any local index has), so that no SUM can wrap
     int add;
 };
 
@@ -257,7 +251,7 @@ __global__ __launch_bounds__(kScatBlock) void k_scatter(ScatterArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t l = x.l[e];
-                bad |= !(__builtin_fabsf(gc[e]) < kFixedLimit) | !(hc[e] < kFixedLimit);  // (NaN compares false)
+                bad |= !(__builtin_fabsf(gc[e]) < a.term_limit) | !(hc[e] < a.term_limit);  // (NaN compares false)
                 atomicAdd(&acc[2 * l], to_fixed(gc[e]));
                 atomicAdd(&acc[2 * l + 1], to_fixed(hc[e]));
             }
@@ -408,6 +402,9 @@ int launch_scatter(ScatterMode mode, const SegStreamDev& s, const void* slice_sr
         a.lidx = s.idx16; a.segid = s.segid; a.seg_delta = s.seg_delta; a.tile_base = s.tile_base; a.val = s.val; a.wg_panel = s.wg_panel; a.tiles_per_span = s.tiles_per_span;
         a.panel_rows = s.panel_rows; a.local_len = s.gather_len; a.slice_src = slice_src; a.global_op = global_op; a.wgacc = s.wgacc;
         a.chunk_lo = s.scat_chunk_lo + s.scat_grp_tab[g]; a.slab0 = s.scat_slab0 + s.scat_grp_wg0[g]; a.slab_bad = s.scat_slab_bad;
+        // (r4) the accumulators hold |x| < 2^27; a per-term bound alone lets a SUM of in-range terms wrap to a finite
+        // wrong value.  With at most scat_max_local_cnt entries per local index, terms below 2^27 / that count cannot.
+        a.term_limit = kFixedLimit / (float) (s.scat_max_local_cnt ? s.scat_max_local_cnt : 1u);
         a.add = add;
         int rc;
         switch (mode) {

@@ -667,6 +667,16 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         rc = build_stores(R, p, space, false);
     }
     MFX_TRY(rc);
+    if (scatter_) {  // bound of a fixed-point sum: the fullest local index of each store = the OTHER store's longest segment
+        for (int side = 0; side < 2; ++side) {
+            SegStreamStore& other = side == 0 ? csc_ : csr_;
+            std::vector<uint32_t> cnt(other.view.nseg);
+            if (!cnt.empty()) MFX_HIP(hipMemcpy(cnt.data(), other.view.seg_cnt, sizeof(uint32_t) * cnt.size(), hipMemcpyDeviceToHost));
+            uint32_t mx = 1;
+            for (uint32_t c : cnt) mx = std::max(mx, c);
+            (side == 0 ? csr_ : csc_).view.scat_max_local_cnt = mx;  // csr_'s local dimension is the columns
+        }
+    }
     if (!scatter_) overlap_groups_ = 1;
     overlap_groups_ = std::min(overlap_groups_, csr_.view.scat_ngroups);
     if (overlap_groups_ > 1) {

@@ -295,6 +295,34 @@ def test_scatter_non_finite_terms_are_not_silently_wrong(mfx):
                 assert np.all(~np.isfinite(b[~np.isfinite(a)])), bad
 
 
+def test_scatter_sums_of_in_range_terms_do_not_wrap(mfx):
+    """the 64-bit fixed-point accumulators (scale 2^36) hold |x| < 2^27.  Checking every TERM against 2^27 is not
+    enough -- a long column of in-range terms sums past it and wraps to a FINITE wrong value.  The per-term bound is
+    2^27 / (entries of the fullest row / column) now, so no sum can wrap: a column of 3000 ratings of 1e6 (terms u r ~ 1e5,
+    each fine on its own, their sum ~ 2e8 > 1.3e8) makes the scatter path go non-finite -- loudly -- instead."""
+    rows, cols = 4000, 300
+    base = mfx.dataset.synth_ratings(rows, cols, 20000, seed=19, test_frac=0.01)
+    r = np.repeat(np.arange(rows), np.diff(base.csr_row_ptr.astype(np.int64)))
+    c = base.csr_col_idx.astype(np.int64)
+    v = base.csr_val.copy()
+    keep = c != 7
+    heavy = np.arange(3000)
+    r, c, v = np.concatenate([r[keep], heavy]), np.concatenate([c[keep], np.full(heavy.size, 7)]), np.concatenate([v[keep], np.full(heavy.size, 1e6, np.float32)])
+    d = mfx.dataset.from_coo(rows, cols, r, c, v.astype(np.float32), base.test_row, base.test_col, base.test_val)
+    out = {}
+    for name, kw in (("flat", {}), ("scatter", {"kernel_variant": 2, "panel_rows": 64})):
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2, 1, 1, **kw))
+        s.set_factors(mfx.initial_col(2, d.rows))
+        s.iterate(1)
+        out[name] = s.get_factors()
+        s.close()
+    assert np.all(np.isfinite(out["flat"][1]))            # fp32 sums hold 2e8 without trouble ...
+    Hs = out["scatter"][1]
+    assert not np.isfinite(Hs[0, 7])                       # ... the fixed-point ones cannot, and say so
+    ok = np.isfinite(Hs[0])
+    assert np.allclose(Hs[0][ok], out["flat"][1][0][ok], rtol=2e-3, atol=1e-5)  # whatever stayed finite is right
+
+
 def test_bad_arguments_are_errors(mfx):
     d = mfx.dataset.synth_ratings(50, 40, 500, seed=1)
     with pytest.raises(mfx.MfxError, match="maxinneriter"):
