@@ -492,6 +492,9 @@ def main() -> None:
         if cand:
             dom = max(cand, key=lambda kn: cand[kn][0])
             secs, launches = cand[dom]
+            # a pass launched by panel groups (sharded scatter column pass): the contract bytes are those of the whole pass
+            per_pass = launches // (a.k * a.steps) if (dom == "ccd_scatter_v_pass" and launches > a.k * a.steps and launches % (a.k * a.steps) == 0) else 1
+            launches //= per_pass
             avg = secs / max(1, launches)
             achieved = alg[dom] / avg / 1e9
             # HBM bytes per launch from the PMC counters: NOT measured in this run (counters need their own rocprofv3
@@ -510,12 +513,12 @@ def main() -> None:
                                               f"{ent.get('collected', '?')}, kernel sources {ent.get('kernel_src_sha16')}")
                         else:
                             traffic_source = ("stale: the kernel sources changed since profiles/traffic.json was collected "
-                                              f"({ent.get('kernel_src_sha16')} -> {kernel_source_hash()}); rerun tools/prof_r03_final.sh")
+                                              f"({ent.get('kernel_src_sha16')} -> {kernel_source_hash()}); rerun tools/prof_final.sh")
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "traffic_source": traffic_source, "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches),
+                        "traffic_source": traffic_source, "avg_launch_us": round(avg * 1e6, 2), "launches": int(launches), "launches_per_pass": int(per_pass),
                         "algorithmic_bytes_per_launch": int(alg[dom]),
                         "streamed_bytes_per_launch": int(phys[dom]) if (dom in phys and (
                             "scatter" in dom or layout["csr" if "csr" in dom else "csc"]["kind"] == "lds")) else int(alg[dom]),
@@ -587,7 +590,7 @@ def main() -> None:
     rows_per_gpu = int(d["rows"])
 
     # ---------------- N > 1: the strong-scaling workload of the north star on the same ranks ----------------
-    strong = None
+    strong_leg = None
     if (world > 1 or a.force_strong) and a.workload == "netflix" and not a.no_strong:
         del d, col_cnt
         torch.cuda.empty_cache()
@@ -597,7 +600,7 @@ def main() -> None:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
             if comm is None:
                 comm = mfx.Comm(mfx.Comm.unique_id(), 0, 1, local_rank)
-        strong = config5_strong_leg(a, torch, dist, mfx, synth_torch, comm, world, rank, local_rank, dev)
+        strong_leg = config5_strong_leg(a, torch, dist, mfx, synth_torch, comm, world, rank, local_rank, dev)
         if world == 1:
             comm.close()
             dist.destroy_process_group()
@@ -624,7 +627,7 @@ def main() -> None:
                        "rows_per_gpu": rows_per_gpu, "cols": a.cols, "nnz_global": nnz_global, "k": a.k,
                        "inner_iters": a.inner, "schedule": "fused" if a.schedule == 1 else "as-written",
                        "parallelism": f"row-block shards x{world}" if world > 1 else "single GPU"},
-            "roofline": roofline, "rank_one_kernel": rank_one, "cpu_baseline": cpu_baseline, "als": als, "config5_strong": strong,
+            "roofline": roofline, "rank_one_kernel": rank_one, "cpu_baseline": cpu_baseline, "als": als, "config5_strong": strong_leg,
             "kernel_src_sha16": kernel_source_hash(), "als_src_sha16": als_source_hash(), "kernels": kernels,
             "allreduce_us_per_inner_iter": (kernels["rccl_allreduce"]["avg_us"] if "rccl_allreduce" in kernels else None),
             # host time to enqueue one outer iteration's launches (+ collectives) in the event-bracketed pass, next to the

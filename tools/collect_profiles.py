@@ -108,6 +108,8 @@ for wl in sorted(os.listdir(src)) if os.path.isdir(src) else []:
     if f:
         rd = list(csv.reader(open(f)))
         csv.writer(open(os.path.join(dst, f"{tag}_kernel_stats_{wl}.csv"), "w")).writerows([rd[0]] + [r for r in rd[1:] if "mfx" in r[0]])
+    for x in sorted(glob.glob(os.path.join(d, "extra_*.txt"))):  # e.g. extra_overlap.txt -> <tag>_overlap_<workload>.txt
+        open(os.path.join(dst, f"{tag}_{os.path.basename(x)[6:-4]}_{wl}.txt"), "w").write(open(x).read())
     pmc_dirs = sorted(p for p in glob.glob(os.path.join(d, "pmc_*")) if os.path.isdir(p))
     if pmc_dirs:
         with open(os.path.join(dst, f"{tag}_pmc_{wl}.txt"), "w") as out:

@@ -30,6 +30,9 @@ want config5   && run_set config5   "--workload config5 --gpus 1 --steps 2 --war
 want config5c  && { O=$F/config5c; rm -rf $O; mkdir -p $O; echo "== config5c"; timeout -k 10 900 python3 bench.py --workload config5 --gpus 1 --steps 2 --warmup 1 --force-comm --no-cpu-baseline --no-rank-one > $O/bench.log 2> $O/bench.err || echo "config5c failed"; }
 want ml1m      && run_set ml1m      "--rows 6040 --cols 3706 --nnz 1000000 --k 40 --steps 100 --warmup 5 --no-als" "--rows 6040 --cols 3706 --nnz 1000000 --k 40 --steps 20 --warmup 5 --no-als"
 want ml100k    && run_set ml100k    "--rows 943 --cols 1682 --nnz 100000 --k 10 --steps 200 --warmup 5 --no-als" "--rows 943 --cols 1682 --nnz 100000 --k 10 --steps 50 --warmup 5 --no-als"
+# the panel-group overlap of the sharded column pass on ONE GPU (1-rank RCCL communicator): bench line, kernel stats, and where the
+# exchange kernels ran relative to the column passes (tools/overlap_from_trace.py on the same kernel trace)
+want shardov   && { export MFX_OVERLAP_GROUPS=2 MFX_COMM_RESERVE_CUS=16; run_set shardov "$SHARD --k 128 --steps 2 --warmup 1 --force-comm --no-cpu-baseline --no-rank-one" "$SHARD --k 8 --steps 2 --warmup 1 --force-comm"; unset MFX_OVERLAP_GROUPS MFX_COMM_RESERVE_CUS; python3 tools/overlap_from_trace.py $F/shardov/stats > $F/shardov/extra_overlap.txt 2>&1 < /dev/null; cat $F/shardov/extra_overlap.txt; }
 want als       && run_set als       "--solver als --steps 3 --warmup 1" "--solver als --steps 2 --warmup 1" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"
 want als128    && run_set als128    "--solver als --k 128 --steps 3 --warmup 1" "--solver als --k 128 --steps 2 --warmup 1"
 echo "prof_final done"
