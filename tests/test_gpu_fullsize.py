@@ -231,6 +231,14 @@ def test_fullsize_k64_ccd_vs_oracle(sigma_cols, rmse_tol, factor_tol):
     assert np.abs(W - Wr).max() < factor_tol * scale and np.abs(H - Hr).max() < factor_tol * scale
     print("fullsize k=64 sigma_cols=%.2f |rmse_product - rmse_reference| = %s ; reference-order mode: bit-identical"
           % (sigma_cols, np.abs(rm - rmse_ref)))
+    # (r4) the reference's OWN acceptance yardstick, golden_compare (src/extras.cpp:218-238: an entry fails when
+    # |x - ref| > 0.1 |ref|), applied to product-path factors against the reference's: what `-CUDA -OMP` prints at this
+    # size.  Reported, not asserted at zero: entries close to zero fail a relative 10 % bar on a 1e-4 absolute difference.
+    for name, A, B in (("W", W, Wr), ("H", H, Hr)):
+        bad = int(np.count_nonzero(np.abs(A.astype(np.float64) - B) > 0.1 * np.abs(B.astype(np.float64))))
+        print("fullsize k=64 sigma_cols=%.2f golden_compare(product, reference) on %s: %s"
+              % (sigma_cols, name, "Check... PASS!" if bad == 0 else "Check... NO PASS! [%.4f%%] #Error = %d out of %d entries." % (100.0 * bad / A.size, bad, A.size)))
+        assert bad < 0.15 * A.size  # (round 2 counted ~6 % of W at the Netflix-like skew)
 
 
 def test_fullsize_k64_als_vs_oracle(big, tmp_path):
