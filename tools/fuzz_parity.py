@@ -61,11 +61,22 @@ for case in range(a.cases):
     elif lay == "scatter":  # persistent workgroups over random chunk ranges (r3)
         p.kernel_variant, p.panel_rows = 2, int(rng.choice([0, 7, 64, 500, 6816]))
         os.environ["MFX_SCATTER_WGS"] = str(int(rng.choice([1, 2, 3, 5, 16, 256, 100000])))
+        # (r4) half of them through the sharded path (1-rank RCCL communicator) with the column pass launched by panel groups
+        use_comm = bool(rng.integers(2))
+        os.environ["MFX_OVERLAP_GROUPS"] = str(int(rng.choice([1, 2, 3, 4, 7, 16])))
+        os.environ["MFX_COMM_RESERVE_CUS"] = str(int(rng.choice([0, 16, 200])))
     elif lay == "reforder":  # the reference's summation order: bit-identical to the oracle (r3)
         p.schedule, p.kernel_variant = 0, -1
     p.tiles_per_span = int(rng.choice([0, 2, 4, 16]))
     p.wg_waves = int(rng.choice([0, 4, 8, 16]))
     p.graph = int(rng.choice([0, -1]))
+    if lay != "scatter":
+        use_comm = False
+    # (r4) the in-pass finalize, now also on the plain layout and its read-only sweeps: opt-in, fuzzed on a third of the cases
+    if rng.integers(3) == 0:
+        os.environ["MFX_FUSE_FINALIZE"] = "1"
+    else:
+        os.environ.pop("MFX_FUSE_FINALIZE", None)
     for env, attr in (("FUZZ_PR", "panel_rows"), ("FUZZ_TPS", "tiles_per_span"), ("FUZZ_WG", "wg_waves"), ("FUZZ_GRAPH", "graph"),
                       ("FUZZ_SCHEDULE", "schedule"), ("FUZZ_T", "maxiter")):  # overrides for bisecting a failing case (--only)
         if env in os.environ:
@@ -77,13 +88,18 @@ for case in range(a.cases):
     try:
         W0 = mfx.initial_col(k, d.rows)
         Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, T, orc.max_threads() if a.big else 2)
-        s = mfx.CcdSolver(d, mfx.test_data_of(d), p)
+        comm = mfx.Comm(mfx.Comm.unique_id(), 0, 1, 0) if use_comm else None
+        gcnt = np.ascontiguousarray(np.diff(d.csc_col_ptr.astype(np.int64)).astype(np.uint32)) if use_comm else None
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), p, comm=comm, global_col_nnz=gcnt, global_test_nnz=d.nnz_test)
         info = s.layout_info()
         s.set_factors(W0.copy())
         rep = s.iterate(t)
         W, H = s.get_factors()
         csc, csr = s.get_residual(d.nnz)
         s.close()
+        if comm is not None:
+            comm.close()
+            kinds["sharded"] = kinds.get("sharded", 0) + 1
         kinds[info["csc"]["kind"]] = kinds.get(info["csc"]["kind"], 0) + 1
         scale = max(1e-6, float(np.abs(Wr).max()), float(np.abs(Hr).max()))
         err = max(float(np.abs(W - Wr).max()), float(np.abs(H - Hr).max())) / scale
