@@ -8,6 +8,7 @@
 #include "ccd_kernels.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -481,6 +482,172 @@ __builtin_nontemporal_store(f32x4{vo[0], vo[1], vo[2], vo[3]}, val4 + tile * 64)
     if constexpr (FUSE) fused_finalize<BLOCK>(a, chunk, lds_raw);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// (r4) Segment-owner fused pass for SMALL matrices (plain layout, a few million ratings at most): pass AND finalize in
+// one launch, without any cross-workgroup step.  Small shapes are launch-bound -- under hipGraph replay a dependent
+// node costs ~4.8 us whether it streams 1e5 or 1e6 ratings (profiles/r04_kernel_stats_ml1m.csv) -- so an outer
+// iteration is (nodes per rank) x k x ~5 us, and the flat-stream form needs four nodes per rank: its nnz-balanced
+// spans cut segments across workgroups, so the sums must meet in a second kernel (k_finalize), and meeting inside
+// the pass ("last workgroup finalizes") costs more than the node it saves (ccd_solver.hpp, fuse_finalize_).  Here a
+// segment has ONE owner instead: a wavefront for a short segment, a whole workgroup for a long one (the lists are
+// made once per store, longest first).  The owner has the complete (g, h), divides, and writes the factor entry and
+// the operand packs of the next passes itself: two nodes per rank.  Measured (profiles/r04_exp_small.txt), ML-1M shape
+// k = 40: 0.795 -> 0.538 ms per outer iteration, ML-100K shape k = 10: 0.188 -> 0.115 ms; the kernel itself takes what
+// the flat pass takes (8.7 vs 8.9 us per eager launch) -- the finalize nodes are simply gone.
+// What mattered on the way (same file): 256-thread workgroups, not 1024 (0.75 -> 0.60 ms: a 16-wave workgroup waits for a
+// CU with that many free slots); one 256-entry tile per wave and round, not two (fewer registers: 0.60 -> 0.54); a long-
+// segment threshold of 1024 entries (256 ... 16384 swept).  What did not: 16-byte against 4-byte accesses, deeper unrolling,
+// the length of the owner's dependent load chain.
+// Per element the arithmetic is element_op's (the reference's unfused update); a sum is added lane by lane over the
+// owner's quads in order, then over the wave on the DPP path, then over the waves in order: fixed, hence bitwise reproducible.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSegOwnerLong = 1024;  // entries from which a segment gets a whole workgroup (a wave walks up to four 256-entry tiles; MFX_OWNER_LONG overrides, A/B)
+#ifndef MFX_OWNER_UL
+#define MFX_OWNER_UL 2
+#define MFX_OWNER_US 1
+#endif
+#ifndef MFX_SEG_BLOCK
+#define MFX_SEG_BLOCK 256
+#endif
+constexpr int kSegBlock = MFX_SEG_BLOCK;
+struct SegOwnerArgs {
+    const uint32_t* ptr;   // [nseg + 1] input-order pointers (plain layout)
+    const uint32_t* idx;
+    float* val;
+    const void* gather;
+    const void* perseg;
+    const uint4* long_list;      // [nlong] (segment, first entry, end, -) one workgroup each
+    const uint4* short_list;     // [nshort] one wavefront each, longest first.  The owner's whole address chain hangs on this ONE
+                                 // load (whose address is known at launch): entry -> indices -> gathered operand, three round trips
+    uint32_t nlong, nshort;
+    float lambda;
+    float* out_vec;
+    float2* pack2;
+    const float* next_vec;
+    float4* pack4;
+};
+
+template <int MODE>
+__device__ __forceinline__ void seg_owner_finish(const SegOwnerArgs& a, uint32_t c, uint32_t cnt, float g, float h,
+                                                 const typename ModeTraits<MODE>::P& ps, float next_old) {
+    // reference: g / (lambda * |Omega| + sum u^2), 0 for an empty segment (src/CCD.cpp:6-16,112)
+    const float x = cnt ? g / add_rn(mul_rn(a.lambda, (float) cnt), h) : 0.f;
+    a.out_vec[c] = x;
+    if constexpr (MODE == FM_FCSC || MODE == FM_FCSR) {  // perseg IS pack2: (prev_new, cur_old) of this segment, read by its owner only
+        if (a.pack4) a.pack4[c] = make_float4(ps.x, ps.y, x, 0.f);
+        a.pack2[c] = make_float2(x, a.next_vec == a.out_vec ? x : next_old);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kSegBlock) void k_seg_owner(SegOwnerArgs a) {
+    using TR = ModeTraits<MODE>;
+    using G = typename TR::G;
+    using P = typename TR::P;
+    const G* __restrict__ gather = static_cast<const G*>(a.gather);
+    const P* __restrict__ perseg = static_cast<const P*>(a.perseg);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float sg[kSegBlock / 64], sh[kSegBlock / 64];
+    // Lane l of a tile owns FOUR CONSECUTIVE entries (one 16-byte load each of indices and values, one 16-byte store), like
+    // the flat kernel: the texture addresser takes ~16 cycles per wave instruction whatever its width, and a first version
+    // with one dword per lane and instruction (40 memory instructions per 512 entries instead of 14) spent the kernel there
+    // (ML-1M shape: 11 us per launch).  A tile starts at a multiple of four entries (16-byte alignment); positions outside
+    // [lo, hi) -- the neighbours' entries in the first / last quad, clamped re-reads past the end -- are masked out of the
+    // sums and never stored (a partial quad is stored entry by entry).  U tiles per round: all index / value loads of a
+    // round go out together, then its 4 U gathers.
+    auto walk = [&](uint32_t lo, uint32_t hi, uint32_t first, uint32_t stride, const P& ps, float& g, float& h, auto unroll) {
+        constexpr int U = decltype(unroll)::value;
+        g = 0.f; h = 0.f;
+        if (hi == lo) return;
+        const uint32_t base = lo & ~3u;
+        uint32_t pq[U];
+        u32x4 id4[U];
+        f32x4 v4[U];
+        auto streams = [&](uint32_t p0, uint32_t (&pp)[U], u32x4 (&ii)[U], f32x4 (&vals)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pp[u] = p0 + (uint32_t) u * 4u * stride;
+                const uint32_t at = pp[u] < hi ? pp[u] : base;  // (clamped: masked below through pp)
+                ii[u] = *reinterpret_cast<const u32x4*>(a.idx + at);
+                vals[u] = *reinterpret_cast<const f32x4*>(a.val + at);
+            }
+        };
+        uint32_t p = base + 4u * first;
+        if (p < hi) streams(p, pq, id4, v4);
+        while (p < hi) {
+            G ga[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ga[u][e] = gather[id4[u][e]];
+            // the next round's streams go out behind this round's gathers: a steady-state round is ONE round trip, not two
+            const uint32_t pn = p + 4u * stride * U;
+            uint32_t pqn[U];
+            u32x4 id4n[U];
+            f32x4 v4n[U];
+            if (pn < hi) streams(pn, pqn, id4n, v4n);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                f32x4 o;
+                bool all_live = true;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t pos = pq[u] + (uint32_t) e;
+                    const bool live = pos >= lo && pos < hi;
+                    all_live &= live;
+                    float vo, gc, hc;
+                    element_op<MODE>(v4[u][e], ga[u][e], ps, 0, vo, gc, hc);
+                    o[e] = vo;
+                    g += live ? gc : 0.f; h += live ? hc : 0.f;
+                }
+                if constexpr (TR::kWrite) {
+                    if (all_live) {
+                        *reinterpret_cast<f32x4*>(a.val + pq[u]) = o;
+                    } else if (pq[u] < hi) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const uint32_t pos = pq[u] + (uint32_t) e; if (pos >= lo && pos < hi) a.val[pos] = o[e]; }
+                    }
+                }
+            }
+            p = pn;
+            if (p < hi) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) { pq[u] = pqn[u]; id4[u] = id4n[u]; v4[u] = v4n[u]; }
+            }
+        }
+    };
+    if (blockIdx.x < a.nlong) {  // ---- a long segment: the whole workgroup
+        const uint4 e = a.long_list[blockIdx.x];
+        const uint32_t c = e.x, lo = e.y, hi = e.z;
+        P ps{};
+        if constexpr (TR::kPerSeg) ps = perseg[c];
+        float g, h;
+        walk(lo, hi, threadIdx.x, kSegBlock, ps, g, h, std::integral_constant<int, MFX_OWNER_UL>{});
+        g = wave_sum(g); h = wave_sum(h);
+        if (lane == 0) { sg[wave] = g; sh[wave] = h; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tg = 0.f, th = 0.f;
+            for (int w = 0; w < kSegBlock / 64; ++w) { tg += sg[w]; th += sh[w]; }
+            seg_owner_finish<MODE>(a, c, hi - lo, tg, th, ps, a.next_vec ? a.next_vec[c] : 0.f);
+        }
+        return;
+    }
+    // ---- short segments: one per wavefront, grid-strided over the list
+    const uint32_t nwaves = (gridDim.x - a.nlong) * (kSegBlock / 64);
+    for (uint32_t q = (blockIdx.x - a.nlong) * (kSegBlock / 64) + wave; q < a.nshort; q += nwaves) {
+        const uint4 e = a.short_list[q];
+        const uint32_t c = e.x, lo = e.y, hi = e.z;
+        P ps{};
+        if constexpr (TR::kPerSeg) ps = perseg[c];
+        const float next_old = a.next_vec ? a.next_vec[c] : 0.f;  // (needed last: fetched first)
+        float g, h;
+        walk(lo, hi, lane, 64, ps, g, h, std::integral_constant<int, MFX_OWNER_US>{});
+        g = wave_sum(g); h = wave_sum(h);
+        if (lane == 0) seg_owner_finish<MODE>(a, c, hi - lo, g, h, ps, next_old);
+    }
+}
 
 // Adds, in span order, the carries that belong to the stored range [lo, hi).  SC1: the partials were written by
 // other workgroups of the SAME launch (fused finalize) and are read past the caches.
@@ -1158,6 +1325,31 @@ int launch_test_r1(int64_t nnz_test, const uint32_t* row, const uint32_t* col, f
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(64), 0, st, nblocks, block_partials, sum_out);
     MFX_LAUNCH_CHECK();
     return MFX_OK;
+}
+
+int launch_seg_owner(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, const FinalizeArgs& f, hipStream_t st) {
+    MFX_REQUIRE(s.panel_rows == 0 && !s.scatter && s.ptr && s.idx && s.own_short && s.own_long, "launch_seg_owner: needs the plain layout with its owner lists");
+    MFX_REQUIRE(!f.gh_dense && !f.cnt_override && !f.pack4_as3 && !f.nmf && !f.fundec_seg, "launch_seg_owner: dense / overridden / extended finalize inputs are not supported");
+    MFX_REQUIRE(mode == FM_SWEEP || ((mode == FM_FCSC || mode == FM_FCSR) && f.pack2 && f.next_vec && f.pack2 == perseg), "launch_seg_owner: bad mode / packs");
+    if (s.nseg == 0) return MFX_OK;
+    SegOwnerArgs a;
+    a.ptr = s.ptr; a.idx = s.idx; a.val = s.val; a.gather = gather; a.perseg = perseg;
+    a.long_list = reinterpret_cast<const uint4*>(s.own_long); a.short_list = reinterpret_cast<const uint4*>(s.own_short); a.nlong = s.own_nlong; a.nshort = s.own_nshort;
+    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
+    const uint32_t short_wgs = std::min<uint32_t>((s.own_nshort + kSegBlock / 64 - 1) / (kSegBlock / 64), 4096u);
+    const dim3 grid(s.own_nlong + short_wgs), block(kSegBlock);
+    if (grid.x == 0) return MFX_OK;
+    switch (mode) {
+        case FM_SWEEP: hipLaunchKernelGGL(k_seg_owner<FM_SWEEP>, grid, block, 0, st, a); break;
+        case FM_FCSC: hipLaunchKernelGGL(k_seg_owner<FM_FCSC>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(k_seg_owner<FM_FCSR>, grid, block, 0, st, a); break;
+    }
+    MFX_LAUNCH_CHECK();
+    return MFX_OK;
+}
+uint32_t seg_owner_long_threshold() {
+    if (const char* e = std::getenv("MFX_OWNER_LONG")) { const int v = std::atoi(e); if (v > 0) return (uint32_t) v; }  // (A/B)
+    return kSegOwnerLong;
 }
 
 }  // namespace mfx

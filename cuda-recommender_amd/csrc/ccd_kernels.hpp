@@ -70,6 +70,10 @@ struct SegStreamDev {
     uint32_t* fz_arrived = nullptr;            // [groups], zero between launches
     const uint32_t* fz_orphans = nullptr;      // [fz_norphans]
     uint32_t fz_norphans = 0, fz_ngroups = 0, fz_max_chunk_groups = 0;
+    // (r4) segment-owner fused passes of small matrices (plain layout; k_seg_owner in ccd_kernels.hip): nullptr = not available
+    const uint32_t* own_long = nullptr;        // [own_nlong][4] (segment, first entry, end, 0) of the segments of >= seg_owner_long_threshold() entries: one workgroup each
+    const uint32_t* own_short = nullptr;       // [own_nshort][4] all other segments, longest first: one wavefront each
+    uint32_t own_nlong = 0, own_nshort = 0;
     // reduction scratch written by the flat kernels
     float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
     float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run
@@ -151,6 +155,10 @@ uint32_t fused_group_size(uint32_t npanels, uint32_t block);
 // FM_FCSC / FM_FCSR pass + the finalize of its sums inside the same launch (s.fz_* must be set; f.gh_dense and
 // f.cnt_override are not supported: sharded column sums go through the all-reduce and the separate kernel)
 int launch_flat_fused(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, const FinalizeArgs& f, hipStream_t st);
+// (r4) pass + finalize of one rank-one half-step in ONE launch, every segment owned by one wavefront / workgroup (small matrices,
+// plain layout): FM_FCSC / FM_FCSR (perseg must be f.pack2) or the read-only FM_SWEEP (perseg nullptr, only f.out_vec is written)
+int launch_seg_owner(FlatMode mode, const SegStreamDev& s, const void* gather, const void* perseg, const FinalizeArgs& f, hipStream_t st);
+uint32_t seg_owner_long_threshold();
 // first / last segment of every workgroup chunk's real entries (0xFFFFFFFF / 0 for a chunk of padding only)
 // wg_spans: spans per workgroup chunk (16 for LDS panels, 4 for the plain layout's 256-thread workgroups)
 int launch_chunk_seg_range(const SegStreamDev& s, uint32_t wg_spans, const uint32_t* panel_end, uint32_t* seg_first, uint32_t* seg_last, hipStream_t st);

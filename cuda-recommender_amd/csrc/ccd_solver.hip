@@ -46,13 +46,41 @@ int SegStreamStore::build(uint32_t nseg, uint64_t nnz, uint32_t G, const uint32_
     if (build_mode != 1) {
         bool done = false;
         MFX_TRY(build_device(nseg, nnz, G, ptr, idx, val, space, opt, st, &done));
-        if (done) { built_on_device_ = true; return build_fuse_tables(st); }
+        if (done) { built_on_device_ = true; MFX_TRY(build_fuse_tables(st)); return build_owner_lists(st); }
         MFX_REQUIRE(build_mode != 2, "layout_build = 2: the pattern is not grouped (some segment visits a panel more than "
                                      "once; sort the indices inside every row / column) -- the device builder cannot take it");
     }
     MFX_REQUIRE(!opt.scatter, "the scatter layout is built by the device pipeline only (pattern not grouped, or layout_build = 1)");
     MFX_TRY(build_host(nseg, nnz, G, ptr, idx, val, space, opt, st));
-    return build_fuse_tables(st);
+    MFX_TRY(build_fuse_tables(st));
+    return build_owner_lists(st);
+}
+
+// (r4) Owner lists of the segment-owner fused passes (k_seg_owner): plain layout of a small matrix only.  Long segments
+// (one workgroup each) and the rest (one wavefront each), both longest first so that the big items start first.
+int SegStreamStore::build_owner_lists(hipStream_t st) {
+    if (view.panel_rows != 0 || view.scatter || view.nseg == 0 || !view.ptr || view.nnz >= 4000000ull) return MFX_OK;
+    std::vector<uint32_t> ptr_h((size_t) view.nseg + 1);
+    MFX_HIP(hipMemcpyAsync(ptr_h.data(), view.ptr, sizeof(uint32_t) * ptr_h.size(), hipMemcpyDeviceToHost, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    std::vector<uint32_t> longs, shorts;
+    const uint32_t thr = seg_owner_long_threshold();
+    for (uint32_t c = 0; c < view.nseg; ++c) (ptr_h[c + 1] - ptr_h[c] >= thr ? longs : shorts).push_back(c);
+    auto by_len = [&](uint32_t x, uint32_t y) { return ptr_h[x + 1] - ptr_h[x] > ptr_h[y + 1] - ptr_h[y]; };
+    std::stable_sort(longs.begin(), longs.end(), by_len);
+    std::stable_sort(shorts.begin(), shorts.end(), by_len);
+    auto quads = [&](const std::vector<uint32_t>& v) {
+        std::vector<uint32_t> out(std::max<size_t>(1, v.size()) * 4, 0u);
+        for (size_t i = 0; i < v.size(); ++i) { out[4 * i] = v[i]; out[4 * i + 1] = ptr_h[v[i]]; out[4 * i + 2] = ptr_h[v[i] + 1]; }
+        return out;
+    };
+    const std::vector<uint32_t> lq = quads(longs), sq = quads(shorts);
+    MFX_TRY(own_long_.alloc(lq.size())); MFX_TRY(own_long_.upload(lq.data(), lq.size(), MFX_HOST, st));
+    MFX_TRY(own_short_.alloc(sq.size())); MFX_TRY(own_short_.upload(sq.data(), sq.size(), MFX_HOST, st));
+    MFX_HIP(hipStreamSynchronize(st));
+    view.own_long = own_long_.get(); view.own_short = own_short_.get();
+    view.own_nlong = (uint32_t) longs.size(); view.own_nshort = (uint32_t) shorts.size();
+    return MFX_OK;
 }
 
 // Fused finalize: which segment groups each workgroup chunk contributes to, how many chunks a group waits for, and
@@ -677,6 +705,11 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
             (side == 0 ? csr_ : csc_).view.scat_max_local_cnt = mx;  // csr_'s local dimension is the columns
         }
     }
+    {   // (r4) small matrices (plain layout on both sides, single GPU, no extensions): segment-owner fused passes
+        const char* e = std::getenv("MFX_OWNER_PASSES");
+        owner_mode_ = !(e && std::atoi(e) == 0) && p->schedule == 1 && p->kernel_variant == 1 && !scatter_ && !(shard && shard->comm) &&
+                      csc_.view.own_short && csr_.view.own_short && !(p->do_nmf || p->eps > 0.f || p->rank_trace);
+    }
     if (!scatter_) overlap_groups_ = 1;
     overlap_groups_ = std::min(overlap_groups_, csr_.view.scat_ngroups);
     if (overlap_groups_ > 1) {
@@ -1006,8 +1039,33 @@ int CcdSolver::rank_fused_scatter(uint32_t t) {
     return MFX_OK;
 }
 
+// (r4) Small matrices: two launches per rank -- every segment has one owner, which finalizes it inside the pass (k_seg_owner).
+int CcdSolver::rank_fused_owner(uint32_t t) {
+    const uint32_t next = (t + 1) % k_;
+    // same invariant as rank_fused: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old)
+    FinalizeArgs fv = fin_base();
+    fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next); fv.pack4 = packC_.get();
+    PROF(KernelProfiler::K_FCSC, launch_seg_owner(FM_FCSC, csc_.view, packA_.get(), packB_.get(), fv, st_));
+    FinalizeArgs fu = fin_base();
+    fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
+    PROF(KernelProfiler::K_FCSR, launch_seg_owner(FM_FCSR, csr_.view, packC_.get(), packA_.get(), fu, st_));
+    for (int it = 2; it <= p_.maxinneriter; ++it) {  // remaining inner iterations: read-only sweeps, finalized by their owners too
+        FinalizeArgs f2 = fin_base(); f2.out_vec = Ht(t);
+        PROF(KernelProfiler::K_SWEEP, launch_seg_owner(FM_SWEEP, csc_.view, Wt(t), nullptr, f2, st_));
+        FinalizeArgs f3 = fin_base(); f3.out_vec = Wt(t);
+        PROF(KernelProfiler::K_SWEEP, launch_seg_owner(FM_SWEEP, csr_.view, Ht(t), nullptr, f3, st_));
+    }
+    if (p_.maxinneriter > 1) {  // the packs must carry the FINAL (u_t, v_t)
+        PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(t), Wt(next), packA_.get(), st_));
+        PROF(KernelProfiler::K_PACK, launch_pack2(n_, Ht(t), Ht(next), packB_.get(), st_));
+    }
+    pending_sub_ = (int32_t) t;
+    return MFX_OK;
+}
+
 int CcdSolver::rank_fused(uint32_t t) {
     if (scatter_) return rank_fused_scatter(t);
+    if (owner_mode_) return rank_fused_owner(t);
     const uint32_t next = (t + 1) % k_;
     // invariant on entry: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old)
     // With MFX_FUSE_FINALIZE=1 the finalize of each pass runs INSIDE the pass (fused_finalize, ccd_kernels.hip);

@@ -37,6 +37,8 @@ private:
                      mfx_memspace space, const FlatLayoutOptions& opt, hipStream_t st, bool* done);
     // group tables of the fused finalize (LDS panels with 16-span workgroups; ccd_kernels.hip, fused_finalize)
     int build_fuse_tables(hipStream_t st);
+    int build_owner_lists(hipStream_t st);  // (r4) segment-owner fused passes of small matrices (plain layout)
+    DevBuf<uint32_t> own_long_, own_short_;
     bool built_on_device_ = false;
     FlatLayoutHost layout_;
     DevBuf<uint32_t> fz_order_, fz_g0_, fz_g1_, fz_expected_, fz_arrived_, fz_orphans_;
@@ -133,6 +135,8 @@ private:
     int fuse_finalize_ = 0;
     bool use_fused(const SegStreamStore& s) const { return fuse_finalize_ == 1 && !ext_on_ && s.can_fuse_finalize(); }
     int rank_fused(uint32_t t);
+    int rank_fused_owner(uint32_t t);  // (r4) small matrices: k_seg_owner, two launches per rank
+    bool owner_mode_ = false;
     int rank_as_written(uint32_t t, bool add_back);
     int flush_pending();
     int sweep(SegStreamStore& s, const float* vec, float* out, bool is_col_side);

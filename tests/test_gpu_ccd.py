@@ -275,9 +275,11 @@ def test_errors_are_reported_not_fatal(mfx, medium):
         mfx.CcdSolver(medium, None, p)
 
 
-def test_sharded_path_single_rank_rccl(mfx, medium):
+def test_sharded_path_single_rank_rccl(mfx, medium, monkeypatch):
     """The multi-GPU code path (combine -> RCCL all-reduce -> finalize from the reduced buffer, fp64
-    all-reduce of the squared error) with a 1-rank communicator must reproduce the unsharded solve."""
+    all-reduce of the squared error) with a 1-rank communicator must reproduce the unsharded solve
+    (of the same kernels: the flat-stream passes -- r4's segment-owner passes of small single-GPU solves add in another order)."""
+    monkeypatch.setenv("MFX_OWNER_PASSES", "0")
     d, k = medium, 8
     W0 = mfx.initial_col(k, d.rows)
     s0 = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, 0.05, 2, 2, 1, 1))
@@ -444,6 +446,7 @@ def test_plain_layout_can_fuse_the_finalize(mfx, medium, monkeypatch):
         return {n: v[1] for n, v in kt.items()}, info
 
     monkeypatch.delenv("MFX_FUSE_FINALIZE", raising=False)
+    monkeypatch.setenv("MFX_OWNER_PASSES", "0")  # (the default for this size -- segment-owner passes -- has its own test below)
     kt, info = launches(0)
     assert info["csc"]["kind"] == "plain" and info["csr"]["kind"] == "plain", info
     assert kt["ccd_finalize"] == 2 * k, kt
@@ -452,6 +455,43 @@ def test_plain_layout_can_fuse_the_finalize(mfx, medium, monkeypatch):
     assert kt.get("ccd_finalize", 0) == 0 and kt["ccd_fused_csc_pass"] == k and kt["ccd_fused_csr_pass"] == k, kt
     kt, _ = launches(0, T=3)
     assert kt.get("ccd_finalize", 0) == 0 and kt["ccd_flat_sweep"] == 4 * k, kt
+
+
+@pytest.mark.parametrize("T", [1, 3])
+def test_small_matrices_take_the_segment_owner_passes(mfx, orc, medium, monkeypatch, T):
+    """(r4) Small single-GPU solves (plain layout on both sides) run two launches per rank: every row / column has ONE owner
+    (a wavefront, or a whole workgroup from 1024 entries on) that walks it, divides and writes the factor entry and the
+    operand packs itself (k_seg_owner) -- no finalize kernel, no cross-workgroup step.  Same element arithmetic as every other
+    path (the residual copies stay bit-identical to each other); the sums are added in the owner's fixed order: oracle
+    tolerances, bitwise reproducible, and the flat-stream path is still there (MFX_OWNER_PASSES=0)."""
+    d, k, lam, t = medium, 6, 0.05, 3
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, *_ = orc.ccdr1(d, W0, k, lam, t, T, orc.max_threads())
+    outs = {}
+    for mode in ("owner", "owner_again", "flat"):
+        if mode == "flat":
+            monkeypatch.setenv("MFX_OWNER_PASSES", "0")
+        else:
+            monkeypatch.delenv("MFX_OWNER_PASSES", raising=False)
+        p = _params(mfx, k, lam, t, T, 1, 1)
+        p.profile = 1
+        s = mfx.CcdSolver(d, mfx.test_data_of(d), p)
+        s.set_factors(W0.copy())
+        rep = s.iterate(t)
+        W, H = s.get_factors()
+        csc, csr = s.get_residual(d.nnz)
+        kt = {n: v[1] for n, v in s.kernel_times().items()}
+        s.close()
+        outs[mode] = (W, H, csc, csr, np.array([r.rmse for r in rep]), kt)
+    W, H, csc, csr, rm, kt = outs["owner"]
+    assert kt.get("ccd_finalize", 0) == 0 and kt["ccd_fused_csc_pass"] == k * t and kt["ccd_fused_csr_pass"] == k * t, kt
+    assert outs["flat"][5]["ccd_finalize"] == 2 * k * t * T
+    assert relerr(W, Wr) < 2e-3 and relerr(H, Hr) < 2e-3 and np.all(np.abs(rm - rmse_ref) < 1e-4)
+    assert all(np.array_equal(bits(a), bits(b)) for a, b in zip(outs["owner"][:4], outs["owner_again"][:4]))  # reproducible
+    # both residual copies hold the same values (same operands, same order of the two updates, in either kernel family)
+    order = np.lexsort((np.repeat(np.arange(d.rows), np.diff(d.csr_row_ptr.astype(np.int64))), d.csr_col_idx))
+    assert np.array_equal(bits(csr[order]), bits(csc))
+    assert relerr(W, outs["flat"][0]) < 1e-3 and relerr(H, outs["flat"][1]) < 1e-3
 
 
 # ---- the flags the reference parses and ignores (-N, -e, -p/-q), opt-in with their LIBPMF meaning ---------------------
