@@ -750,6 +750,12 @@ struct FinKernelArgs {
     const uint32_t* seg_cnt;
     const float* gh_dense;
     uint32_t seg_base, gh_len;  // dense source: segments [seg_base, seg_base + gh_len), g then h in gh_dense (a panel group)
+    // ... or (r4) the fixed-point slabs of a scatter pass themselves: k_scatter_combine's sum and conversion done here, no dense
+    // buffer and no combine launch in between (whenever no all-reduce sits between the pass and its finalize)
+    const unsigned long long* slab_acc;
+    const uint32_t* slab_lo;
+    const uint32_t* slab_bad;
+    uint32_t slab_pr;
     const uint32_t* cnt_override;
     float lambda;
     float* out_vec;
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     // old pack entry, next vector entry) before the partial sums are chased, so that those loads do
     // not queue up behind the rank -> part -> (barrier) chain.
     constexpr int SEGS = kBlock / PL;
-    const bool flat = !a.gh_dense;
+    const bool flat = !a.gh_dense && !a.slab_acc;
     const uint32_t dl = blockIdx.x * kBlock + threadIdx.x;  // dense source: index inside the group's block
     const uint32_t c0 = flat ? blockIdx.x * SEGS + threadIdx.x % SEGS : a.seg_base + dl;
     const bool owner = flat ? (c0 < a.parts.nseg && threadIdx.x / SEGS == 0) : dl < a.gh_len;
@@ -780,7 +786,21 @@ __global__ __launch_bounds__(kBlock) void k_finalize(FinKernelArgs a) {
     }
     uint32_t c;
     float g, h;
-    if (a.gh_dense) {  // PL == 1 by construction
+    if (a.slab_acc) {  // the slabs of the panel of c, added as integers (any order: the same bits), exactly as k_scatter_combine does
+        c = c0;
+        if (dl >= a.gh_len) return;
+        const uint32_t p = c / a.slab_pr, l = c - p * a.slab_pr;
+        unsigned long long ig = 0, ih = 0;
+        uint32_t bad = 0;
+        for (uint32_t w = a.slab_lo[p]; w < a.slab_lo[p + 1]; ++w) {
+            const unsigned long long* sl = a.slab_acc + (size_t) w * 2 * a.slab_pr + 2 * l;
+            ig += sl[0]; ih += sl[1];
+            bad |= a.slab_bad[w];
+        }
+        constexpr double inv = 1.0 / 68719476736.0;  // 2^-36 (ccd_scatter.hip, to_fixed)
+        g = bad ? __builtin_nanf("") : (float) ((double) (long long) ig * inv);
+        h = bad ? __builtin_nanf("") : (float) ((double) (long long) ih * inv);
+    } else if (a.gh_dense) {  // PL == 1 by construction
         c = c0;
         if (dl >= a.gh_len) return;
         g = a.gh_dense[dl];
@@ -1256,10 +1276,17 @@ int launch_finalize(const SegStreamDev& s, const FinalizeArgs& f, hipStream_t st
     FinKernelArgs a;
     a.parts = parts_of(s); a.seg_cnt = s.seg_cnt; a.gh_dense = f.gh_dense; a.cnt_override = f.cnt_override;
     a.seg_base = f.gh_len ? f.seg_base : 0u; a.gh_len = f.gh_len ? f.gh_len : s.nseg;
-    MFX_REQUIRE(!f.gh_len || (f.gh_dense && (uint64_t) f.seg_base + f.gh_len <= s.nseg), "launch_finalize: bad segment range %u + %u of %u", f.seg_base, f.gh_len, s.nseg);
+    a.slab_acc = nullptr; a.slab_lo = nullptr; a.slab_bad = nullptr; a.slab_pr = 1;
+    if (f.slab_src) {
+        MFX_REQUIRE(!f.gh_dense && f.slab_src->scatter && f.slab_src->wgacc && f.slab_src->slab_lo && f.slab_src->scat_slab_bad && f.slab_src->gather_len == s.nseg,
+                    "launch_finalize: bad slab source");
+        a.slab_acc = f.slab_src->wgacc; a.slab_lo = f.slab_src->slab_lo; a.slab_bad = f.slab_src->scat_slab_bad; a.slab_pr = f.slab_src->panel_rows;
+    }
+    MFX_REQUIRE(!f.gh_len || ((f.gh_dense || f.slab_src) && (uint64_t) f.seg_base + f.gh_len <= s.nseg), "launch_finalize: bad segment range %u + %u of %u", f.seg_base, f.gh_len, s.nseg);
     a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4; a.pack4_as3 = f.pack4_as3; a.nmf = f.nmf; a.fundec_seg = f.fundec_seg;
-    const int pl = f.gh_dense ? 1 : panel_lanes(s);
-    const uint32_t nfin = f.gh_dense ? a.gh_len : s.nseg;
+    const bool dense = f.gh_dense || f.slab_src;
+    const int pl = dense ? 1 : panel_lanes(s);
+    const uint32_t nfin = dense ? a.gh_len : s.nseg;
     if (nfin == 0) return MFX_OK;
     const dim3 grid((nfin + kBlock / pl - 1) / (kBlock / pl)), block(kBlock);
     if (pl == 16) hipLaunchKernelGGL(k_finalize<16>, grid, block, 0, st, a);

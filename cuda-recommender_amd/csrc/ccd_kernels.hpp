@@ -131,6 +131,9 @@ struct FinalizeArgs {
     // dense source restricted to the segments [seg_base, seg_base + gh_len) (a panel group of the scatter pass): gh_dense
     // then points at that group's block -- gh_len sums g, then gh_len sums h; gh_len = 0 means all nseg segments
     uint32_t seg_base = 0, gh_len = 0;
+    // (r4) ... or the slabs of the scatter pass that just streamed `slab_src` (its gathered dimension = these segments): combine and
+    // finalize in one launch, bit-identical to launch_scatter_combine + the dense form (gh_dense must be nullptr)
+    const struct SegStreamDev* slab_src = nullptr;
     const uint32_t* cnt_override = nullptr;  // global |Omega_c| (multi-GPU) or nullptr = local count
     float lambda = 0.f;
     float* out_vec = nullptr;           // W[t] / H[t] slice, [nseg]

@@ -906,14 +906,16 @@ int CcdSolver::scatter_finalize(bool cols, const FinalizeArgs& base, int group, 
     for (uint32_t g = group < 0 ? 0u : (uint32_t) group; g < (group < 0 ? v.scat_ngroups : (uint32_t) group + 1); ++g) {
         const uint32_t lo = v.scat_grp_lo[g], hi = v.scat_grp_lo[g + 1];
         if (hi <= lo) continue;
-        PROFS(KernelProfiler::K_SCAT_COMBINE, st, launch_scatter_combine(v, gh, st, (int) g));
         FinalizeArgs f = base;
-        f.gh_dense = gh + 2 * (size_t) lo;  // the group's block: g of [lo, hi), then h
         f.seg_base = lo; f.gh_len = hi - lo;
         f.cnt_override = (cols ? csc_ : csr_).view.seg_cnt;  // |Omega| of the reduced dimension = the OTHER store's segment counts
-        if (cols && comm_) {
+        if (cols && comm_) {  // the sums leave the GPU in between: slabs -> dense (g, h) -> all-reduce -> finalize from the reduced buffer
+            PROFS(KernelProfiler::K_SCAT_COMBINE, st, launch_scatter_combine(v, gh, st, (int) g));
+            f.gh_dense = gh + 2 * (size_t) lo;  // the group's block: g of [lo, hi), then h
             PROFS(KernelProfiler::K_ALLREDUCE, st, comm_allreduce_f32(comm_, gh + 2 * (size_t) lo, (size_t) 2 * (hi - lo), st));
             f.cnt_override = global_col_nnz_.get();
+        } else {              // (r4) nothing in between: the finalize adds the slabs itself (one launch, the same bits)
+            f.slab_src = &v;
         }
         out_view.seg_cnt = f.cnt_override;
         PROFS(KernelProfiler::K_FINALIZE, st, launch_finalize(out_view, f, st));
