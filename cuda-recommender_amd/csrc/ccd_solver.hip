@@ -681,12 +681,14 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     // of LDS and ~280 registers per lane, and neither fits next to a scatter workgroup (150 KB of LDS, 4 x 112 registers per
     // SIMD lane), so the column pass leaves `reserve` CUs free.  MFX_OVERLAP_GROUPS (1 = off) / MFX_COMM_RESERVE_CUS.
     if (shard && shard->comm) {
-        const int nr = shard->comm->nranks;
-        int groups = nr > 1 ? 2 : 1, reserve = -1;
+        // Off by default: two groups cost ~60-85 us per rank-one update on one GPU; whether the half of the
+        // all-reduce they hide is longer than that can only be measured on more than one GPU -- bench.py's config5_strong leg
+        // does, with 1 and with 2 groups, and keeps the better.
+        int groups = 1, reserve = -1;
         if (const char* e = std::getenv("MFX_OVERLAP_GROUPS")) groups = std::atoi(e);
         if (const char* e = std::getenv("MFX_COMM_RESERVE_CUS")) reserve = std::atoi(e);
         overlap_groups_ = (uint32_t) std::max(1, std::min(groups, (int) SegStreamDev::kMaxScatterGroups));
-        if (reserve < 0) reserve = (overlap_groups_ > 1 && nr > 1) ? 16 : 0;
+        if (reserve < 0) reserve = overlap_groups_ > 1 ? 16 : 0;
         comm_reserve_cus_ = overlap_groups_ > 1 ? (uint32_t) reserve : 0u;
     }
     int rc = build_stores(R, p, space, want_scatter);
