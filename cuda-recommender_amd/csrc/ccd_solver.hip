@@ -709,8 +709,13 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
     }
     {   // (r4) small matrices (plain layout on both sides, single GPU, no extensions): segment-owner fused passes
         const char* e = std::getenv("MFX_OWNER_PASSES");
-        owner_mode_ = !(e && std::atoi(e) == 0) && p->schedule == 1 && p->kernel_variant == 1 && !scatter_ && !(shard && shard->comm) &&
-                      csc_.view.own_short && csr_.view.own_short && !(p->do_nmf || p->eps > 0.f || p->rank_trace);
+        // ... as long as there are few enough segments: one wavefront per segment means (rows + columns) waves per rank, and a wave
+        // of a 20-entry row fills 8 % of its lanes.  Measured under graph replay (profiles/r04_exp_small.txt, owner vs flat, ms per
+        // outer iteration): 6040 x 3706 0.54 / 0.79, 20 000 x 8 000 0.89 / 1.04, 30 000 x 10 000 (3.9 M ratings) 1.38 / 1.87 -- but
+        // 70 000 x 2 000 2.00 / 1.79, 2 000 x 70 000 1.95 / 1.77, 200 000 x 100 000 2.07 / 1.17.  MFX_OWNER_PASSES=1 forces, 0 forbids.
+        const bool few_segments = std::max(m_, n_) <= 40000u;
+        owner_mode_ = !(e && std::atoi(e) == 0) && (few_segments || (e && std::atoi(e) == 1)) && p->schedule == 1 && p->kernel_variant == 1 && !scatter_ &&
+                      !(shard && shard->comm) && csc_.view.own_short && csr_.view.own_short && !(p->do_nmf || p->eps > 0.f || p->rank_trace);
     }
     if (!scatter_) overlap_groups_ = 1;
     overlap_groups_ = std::min(overlap_groups_, csr_.view.scat_ngroups);
