@@ -1,0 +1,10 @@
+#!/bin/bash
+# (r4) mid-size shapes of the reference's own protocol (scripts/times.sh: ml10M, ml20M, K up to 50)
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r4; mkdir -p $O
+out=$O/exp_mid.txt; : > $out
+line() { python3 -c "import sys,json; b=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); k=b['kernels']; print('$1', 'ms_per_step', b['ms_per_step'], {n: v['avg_us'] for n, v in k.items() if 'pass' in n or 'final' in n}, b['layout'])"; }
+for shape in "69878 10677 10000054 40" "138493 26744 20000263 40" "71567 65133 10000054 40"; do
+  set -- $shape
+  env $EXTRA python3 bench.py --rows $1 --cols $2 --nnz $3 --k $4 --steps 10 --warmup 2 --no-cpu-baseline --no-rank-one --no-als 2>$O/err_mid.txt | line "$1x$2 nnz=$3 k=$4 $EXTRA" >> $out || tail -2 $O/err_mid.txt >> $out
+done
+cat $out
