@@ -117,8 +117,9 @@ int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float*
 // Reference-order sweep (ccd_reforder.hip; plain layout only): out[c] = g / h with g and h accumulated strictly left to
 // right in unfused fp32 from (0, lambda * count) -- RankOneUpdate_Original_float (src/CCD.cpp:6-16) bit for bit.
 // order: dispatch order of the segments (ref_sweep_order: longest first) or nullptr (ascending).
-int launch_sweep_ref(const SegStreamDev& s, const uint32_t* order, const float* vec, float lambda, float* out, hipStream_t st);
-void ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<uint32_t>* order);
+// nlong: the leading `order` entries that take the two-wave plain-add form (ref_sweep_order's return value; 0 with order == nullptr)
+int launch_sweep_ref(const SegStreamDev& s, const uint32_t* order, uint32_t nlong, const float* vec, float lambda, float* out, hipStream_t st);
+uint32_t ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<uint32_t>* order);
 
 // partials + carries of a flat pass -> dense gh[0..nseg) = g, gh[nseg..2nseg) = h (0 for empty).
 int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st);

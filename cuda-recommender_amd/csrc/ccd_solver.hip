@@ -730,7 +730,7 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
             std::vector<uint32_t> ptr_h((size_t) v.nseg + 1), order;
             MFX_HIP(hipMemcpyAsync(ptr_h.data(), v.ptr, sizeof(uint32_t) * ptr_h.size(), hipMemcpyDeviceToHost, st_));
             MFX_HIP(hipStreamSynchronize(st_));
-            ref_sweep_order(ptr_h.data(), v.nseg, &order);
+            (side == 0 ? ref_nlong_csc_ : ref_nlong_csr_) = ref_sweep_order(ptr_h.data(), v.nseg, &order);
             DevBuf<uint32_t>& dst = side == 0 ? ref_order_csc_ : ref_order_csr_;
             MFX_TRY(dst.alloc(order.size()));
             MFX_TRY(dst.upload(order.data(), order.size(), MFX_HOST, st_));
@@ -1147,7 +1147,7 @@ int CcdSolver::sweep(SegStreamStore& s, const float* vec, float* out, bool is_co
         return scatter_finalize(is_col_side, f);
     }
     if (ref_order_) {  // g, h and the division in one kernel, in the reference's order; no separate finalize
-        PROF(KernelProfiler::K_SWEEP_REF, launch_sweep_ref(s.view, (is_col_side ? ref_order_csc_ : ref_order_csr_).get(), vec, p_.lambda, out, st_));
+        PROF(KernelProfiler::K_SWEEP_REF, launch_sweep_ref(s.view, (is_col_side ? ref_order_csc_ : ref_order_csr_).get(), is_col_side ? ref_nlong_csc_ : ref_nlong_csr_, vec, p_.lambda, out, st_));
         return MFX_OK;
     }
     if (p_.kernel_variant == 0) {

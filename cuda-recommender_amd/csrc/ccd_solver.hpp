@@ -147,6 +147,7 @@ private:
     // kernel_variant = -1: sweeps in the reference's summation order (ccd_reforder.hip), bit-identical to src/CCD.cpp
     bool ref_order_ = false;
     DevBuf<uint32_t> ref_order_csc_, ref_order_csr_;  // segments, longest first
+    uint32_t ref_nlong_csc_ = 0, ref_nlong_csr_ = 0;  // ... of which this many take the two-wave plain-add form (ccd_reforder.hip)
     // slabs -> dense (g,h) -> [all-reduce] -> finalize, for one panel group of the streamed store (-1: all), on `st` (nullptr: st_)
     int scatter_finalize(bool cols, const FinalizeArgs& base, int group = -1, hipStream_t st = nullptr);
     // (r4) overlap of the column-side exchange with the column pass (sharded solve, scatter layout): see init()
