@@ -1131,6 +1131,7 @@ int CcdSolver::flush_pending() {
     const uint32_t t = (uint32_t) pending_sub_, next = (t + 1) % k_;
     MFX_TRY(resid(csc_, Wt(t), Ht(t), 0));
     MFX_TRY(resid(csr_, Ht(t), Wt(t), 0));
+    if (ref_order_) { pending_sub_ = -1; return MFX_OK; }  // (the operand packs below belong to the fused schedule)
     PROF(KernelProfiler::K_PACK, launch_pack2(m_, nullptr, Wt(next), packA_.get(), st_));
     PROF(KernelProfiler::K_PACK, launch_pack2(n_, nullptr, Ht(next), packB_.get(), st_));
     pending_sub_ = -1;
@@ -1184,6 +1185,37 @@ int CcdSolver::resid(SegStreamStore& s, const float* gathered, const float* per_
 int CcdSolver::rank_as_written(uint32_t t, bool add_back) {
     float* u = Wt(t);
     float* v = Ht(t);
+    if (ref_order_) {
+        // (r4) reference-order mode: the subtraction of rank t - 1 and the add-back of rank t are two consecutive elementwise passes
+        // over the same copy (src/CCD.cpp:100-134) -- applied in ONE pass per copy, in the same order and with the same two roundings
+        // per element (element_op<FM_FCSC>: (r - a b) + c d, unfused), so every stored residual keeps the reference's bits while the
+        // mode streams each copy once per rank instead of twice.  The subtraction of a rank stays pending until the next rank (or a
+        // reader of the residual: flush_pending) applies it.
+        if (pending_sub_ >= 0) {
+            const uint32_t prev = (uint32_t) pending_sub_;
+            if (add_back) {
+                PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(prev), u, packA_.get(), st_));
+                PROF(KernelProfiler::K_PACK, launch_pack2(n_, Ht(prev), v, packB_.get(), st_));
+                PROF(KernelProfiler::K_RESID, launch_flat(FM_FCSC, csc_.view, packA_.get(), packB_.get(), 0, st_));  // (its sums are not used)
+                PROF(KernelProfiler::K_RESID, launch_flat(FM_FCSC, csr_.view, packB_.get(), packA_.get(), 0, st_));
+            } else {
+                MFX_TRY(resid(csc_, Wt(prev), Ht(prev), 0));
+                MFX_TRY(resid(csr_, Ht(prev), Wt(prev), 0));
+            }
+            pending_sub_ = -1;
+        } else if (add_back) {
+            MFX_TRY(resid(csc_, u, v, 1));
+            MFX_TRY(resid(csr_, v, u, 1));
+        }
+        bool stop = false;
+        for (int it = 1; it <= p_.maxinneriter && !stop; ++it) {
+            MFX_TRY(sweep(csc_, u, v, true));
+            MFX_TRY(sweep(csr_, v, u, false));
+            MFX_TRY(inner_stop(t, it, &stop));
+        }
+        pending_sub_ = (int32_t) t;
+        return MFX_OK;
+    }
     if (add_back) {
         MFX_TRY(resid(csc_, u, v, 1));
         MFX_TRY(resid(csr_, v, u, 1));
@@ -1369,6 +1401,7 @@ int CcdSolver::get_residual(float* csc_val, float* csr_val) {
         MFX_HIP(hipMemcpyAsync(out, tmp.get(), sizeof(float) * nnz_, hipMemcpyDeviceToHost, st_));
         MFX_HIP(hipStreamSynchronize(st_));
     }
+    MFX_HIP(hipStreamSynchronize(st_));  // (an empty matrix copies nothing above, but flush_pending may have recorded launch events)
     MFX_TRY(prof_.collect());
     return MFX_OK;
 }

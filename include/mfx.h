@@ -87,7 +87,7 @@ typedef struct mfx_params {
     int32_t kernel_variant;    /* -1 = REFERENCE-ORDER parity mode (schedule 0 only, single GPU): every rank-one sum is added strictly
                                   left to right in unfused fp32 exactly like src/CCD.cpp:6-16 -- W, H and both residual copies come out
                                   bit-identical to the reference's CPU solver (csrc/ccd_reforder.hip; the CCD++ counterpart of ALS
-                                  schedule 0); ~10x slower than the default path;
+                                  schedule 0; the subtraction of a rank and the add-back of the next are applied in one pass, same roundings); ~8x slower than the default path;
                                   0 = wave-per-segment kernels (schedule 0 only), 1 = flat-stream kernels (default),
                                   2 = force the scatter layout (csrc/ccd_scatter.hip), which hyper-sparse shapes
                                   get on their own: < 8 entries per (LDS panel, row / column) pair;
