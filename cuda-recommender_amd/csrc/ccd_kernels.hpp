@@ -74,6 +74,7 @@ struct SegStreamDev {
     const uint32_t* own_long = nullptr;        // [own_nlong][4] (segment, first entry, end, 0) of the segments of >= seg_owner_long_threshold() entries: one workgroup each
     const uint32_t* own_short = nullptr;       // [own_nshort][4] all other segments, longest first: one wavefront each
     uint32_t own_nlong = 0, own_nshort = 0;
+    uint32_t own_max_len = 0;                  // the longest segment (the owner form gives balance up: the solver declines it beyond 65536 entries)
     // reduction scratch written by the flat kernels
     float2* part = nullptr;    // [nne] (g, h) per non-empty virtual segment
     float2* carry = nullptr;   // [nspans] (g, h) of a span's leading run

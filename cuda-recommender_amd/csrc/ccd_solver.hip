@@ -80,6 +80,7 @@ int SegStreamStore::build_owner_lists(hipStream_t st) {
     MFX_HIP(hipStreamSynchronize(st));
     view.own_long = own_long_.get(); view.own_short = own_short_.get();
     view.own_nlong = (uint32_t) longs.size(); view.own_nshort = (uint32_t) shorts.size();
+    for (uint32_t c = 0; c < view.nseg; ++c) view.own_max_len = std::max(view.own_max_len, ptr_h[c + 1] - ptr_h[c]);
     return MFX_OK;
 }
 
@@ -713,7 +714,8 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         // of a 20-entry row fills 8 % of its lanes.  Measured under graph replay (profiles/r04_exp_small.txt, owner vs flat, ms per
         // outer iteration): 6040 x 3706 0.54 / 0.79, 20 000 x 8 000 0.89 / 1.04, 30 000 x 10 000 (3.9 M ratings) 1.38 / 1.87 -- but
         // 70 000 x 2 000 2.00 / 1.79, 2 000 x 70 000 1.95 / 1.77, 200 000 x 100 000 2.07 / 1.17.  MFX_OWNER_PASSES=1 forces, 0 forbids.
-        const bool few_segments = std::max(m_, n_) <= 40000u;
+        // ... and no segment so long that its one owner becomes the whole pass (a 256-thread workgroup walks 2048 entries per round)
+        const bool few_segments = std::max(m_, n_) <= 40000u && std::max(csc_.view.own_max_len, csr_.view.own_max_len) <= 65536u;
         owner_mode_ = !(e && std::atoi(e) == 0) && (few_segments || (e && std::atoi(e) == 1)) && p->schedule == 1 && p->kernel_variant == 1 && !scatter_ &&
                       !(shard && shard->comm) && csc_.view.own_short && csr_.view.own_short && !(p->do_nmf || p->eps > 0.f || p->rank_trace);
     }
