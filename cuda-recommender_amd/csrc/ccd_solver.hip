@@ -508,10 +508,20 @@ FlatLayoutOptions choose_layout(const mfx_params& p, uint32_t nseg, uint64_t nnz
     // 40/48/56/64/72 KB give 30.1/29.9/28.0/29.1/28.4 ms per outer iteration.
     // (round 2, 12-byte CSR slice entries, CSC / CSR pass per launch: 48 KB 199 / 230 us, 56 KB 183 / 191, 64 KB 187 / 231,
     // 71 KB 187 / 192 -- profiles/r02_exp_slice.txt)
-    constexpr uint32_t slice_kb = 56;
+    uint32_t slice_kb = 56;
+    if (const char* e = std::getenv("MFX_SLICE_KB")) { const int v = std::atoi(e); if (v >= 8 && v <= 150) slice_kb = (uint32_t) v; }  // (A/B)
     uint32_t pr = p.panel_rows > 0 ? (uint32_t) p.panel_rows : (slice_kb * 1024u) / elem_bytes - 1;
     if (pr >= G) pr = G;  // the whole gathered vector fits: one panel
     const uint64_t npanels = (G + pr - 1) / pr;
+    // (r4) EQUAL panels: the same count, but ceil(G / npanels) entries each instead of full slices and a remainder.  A short last
+    // panel is a load imbalance (its workgroups finish early), and the smaller slices can let a third workgroup onto a CU (ML-10M
+    // shape, CSR copy: 4777 / 4777 / 1123 columns -> 3 x 3559: 51 instead of 64 KB of LDS per workgroup): fused CSR pass 37.9 -> 26.5 us,
+    // outer iteration at k = 40 2.78 -> 2.32 ms; ML-20M shape 5.07 -> 4.47 ms; 300 000 x 40 000 with 3e7 ratings 6.36 -> 5.67 ms;
+    // Netflix shape 25.0 -> 24.9 ms (profiles/r04_exp_midsize.txt).  MFX_EQUAL_PANELS=0: full slices + remainder (A/B).
+    if (p.panel_rows == 0 && npanels > 1) {
+        const char* e = std::getenv("MFX_EQUAL_PANELS");
+        if (!(e && std::atoi(e) == 0)) pr = (uint32_t) ((G + npanels - 1) / npanels);
+    }
     const double mean_vseg = (double) nnz / ((double) npanels * (double) (nseg ? nseg : 1));
     // ... unless the matrix is small enough that the per-(panel, segment) bookkeeping stays cheap: up to 8 M virtual
     // segments the LDS panels still win (700 000 x 40 000 with 3e7 / 1.5e7 / 8e6 ratings, 7.1 / 3.6 / 1.9 entries per
