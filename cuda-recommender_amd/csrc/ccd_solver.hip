@@ -844,6 +844,7 @@ int CcdSolver::build_stores(const mfx_csx* R, const mfx_params* p, mfx_memspace 
                     if (q / gcd(q, c / groups) <= 2) { P = c; break; }
             }
             if (P == 0 && groups > 1 && p0 >= groups) P = (p0 + groups - 1) / groups * groups;  // equal groups at least
+            if (P == 0 && align && p0 > 1) P = p0;  // few panels: the same count, equal sizes (no short last panel)
             if (P) o.panel_rows = (G + P - 1) / P;
         }
         // spans of 4 tiles when the matrix is large: with persistent workgroups (ccd_scatter.hip) the span length only

@@ -121,8 +121,8 @@ def test_hyper_sparse_shard_layouts(mfx, orc):
     s.close()
     assert info["csc"]["kind"] == "scatter" and info["csr"]["kind"] == "scatter", info
     # (r4) phase alignment: at least CUs / 8 LDS-sized panels -> the count is rounded up to a multiple of CUs / 8
-    # (600 k rows: 89 panels of 6816 -> 96 of 6250); fewer panels than that keep the largest panel the LDS holds
-    assert info["csc"]["panels"] == 96 and info["csc"]["panel_rows"] == 6250 and info["csr"]["panel_rows"] == 6816, info
+    # (600 k rows: 89 panels of 6816 -> 96 of 6250); fewer panels than that keep their count, in equal sizes (40 k columns: 6 x 6667)
+    assert info["csc"]["panels"] == 96 and info["csc"]["panel_rows"] == 6250 and info["csr"]["panels"] == 6 and info["csr"]["panel_rows"] == 6667, info
     s = mfx.CcdSolver(d, mfx.test_data_of(d), _p(mfx, 2, layout_build=1))
     info = s.layout_info()
     s.close()
