@@ -817,7 +817,14 @@ __device__ __forceinline__ void stage_tiles16_perm(f32x4 (&acc)[kTiles16], float
 }
 
 // Pipeline state of k_als_gram16: D register sets, used in turn by consecutive 16-row steps (no copies).
-constexpr int kU16 = 4;  // 4-row MFMA groups per step: 16 gathered rows (4 KB) per set
+// (r4) two 4-row groups per step (8 gathered rows, 2 KB per set) instead of four: the loop's register sets halve, and a tail-dominated
+// launch then fits FOUR waves per SIMD (128 VGPRs, 44 bytes of scratch per lane) -- user half of the Netflix shape 7.67 -> 7.26 ms, iteration
+// 12.80 -> 12.30 ms; (waves, groups) = (3, 2) 12.80, (4, 4) 12.46, (5, 2) 21.3 (264 bytes of scratch), (4, 1) 13.3 (tools/exp_als_libs.sh)
+#ifndef MFX_G16_U
+#define MFX_G16_U 2
+#endif
+constexpr int kU16 = MFX_G16_U;  // 4-row MFMA groups per step
+constexpr uint32_t kRows16 = 4u * kU16;
 template <int D>
 struct Gram16Regs {
     uint32_t ix[D][kU16];  // gathered row indices           (stage 0: loaded D steps ahead of their MFMAs)
@@ -836,7 +843,7 @@ struct Gram16Regs {
 template <int D, int S>
 __device__ __forceinline__ void g16_load_idx(Gram16Regs<D>& r, const uint32_t* __restrict__ ibase, uint32_t s, uint32_t g) {
 #pragma unroll
-    for (int u = 0; u < kU16; ++u) r.ix[S][u] = ibase[s * 16 + 4 * u + g];
+    for (int u = 0; u < kU16; ++u) r.ix[S][u] = ibase[s * kRows16 + 4 * u + g];
 }
 template <int D, int S>
 __device__ __forceinline__ void g16_load_rows(Gram16Regs<D>& r, const char* __restrict__ Xb, const float* __restrict__ vbase,
@@ -844,14 +851,14 @@ __device__ __forceinline__ void g16_load_rows(Gram16Regs<D>& r, const char* __re
                                               uint32_t lane_off, uint32_t zero_off) {
 #pragma unroll
     for (int u = 0; u < kU16; ++u) {
-        const bool ok = col_ok && s * 16 + 4 * u + g < len;
+        const bool ok = col_ok && s * kRows16 + 4 * u + g < len;
         uint32_t ix = r.ix[S][u];
         // opaque use: otherwise the index load (only consumed when `ok`) is sunk out of the previous step into a
         // divergent branch right here, with a full wait behind it
         asm volatile("" : "+v"(ix));
         const uint32_t off = ok ? __umul24(ix, rowbytes) + lane_off : zero_off;  // x_rows < 2^24, table < 4 GB (launch_half)
         r.av[S][u] = *reinterpret_cast<const f32x4*>(Xb + off);
-        r.rv[S][u] = vbase[s * 16 + 4 * u + g];
+        r.rv[S][u] = vbase[s * kRows16 + 4 * u + g];
     }
 }
 template <int D, int S>
@@ -892,7 +899,7 @@ __device__ __forceinline__ bool g16_steps(Gram16Regs<D>& r, const Gram16Ctx& c, 
         __builtin_amdgcn_sched_barrier(0);
         g16_mfma<D, U>(r);
         __builtin_amdgcn_sched_barrier(0);
-        if (++s * 16 >= c.len) return true;
+        if (++s * kRows16 >= c.len) return true;
         return g16_steps<D, U + 1>(r, c, s);
     } else {
         return false;
@@ -916,7 +923,7 @@ __device__ __forceinline__ void g16_prologue(Gram16Regs<D>& r, const Gram16Ctx& 
 // rate whether the gather is served from HBM, L2 or L1 -- the rest of a half-sweep is the per-system tail.
 // WAVES per SIMD: a launch whose items are long (the item half: 2048-row chunks, hardly any tails) is fastest with
 // TWO waves per SIMD (5.42 -> 4.91 ms at the Netflix shape), one dominated by per-system tails (the user half, 206
-// entries per system) wants the latency hiding of three or four (7.9 ms; 9.2 ms at two).  Three = 168 VGPRs, no
+// entries per system) wants the latency hiding of three or four (7.9 ms; 9.2 ms at two; r4: four, see kU16).  Three = 168 VGPRs, no
 // spills; four = 128 VGPRs + 18 spilled dwords, same time.
 template <int WAVES, int D, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_als_gram16(AlsArgs a) {
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(64) void k_als_reduce16(AlsArgs a) {
 #ifndef MFX_G16_WL
 #define MFX_G16_WL 2
 #define MFX_G16_DL 2
-#define MFX_G16_WS 3
+#define MFX_G16_WS 4
 #define MFX_G16_DS 2
 #endif
 int launch_half_16(const AlsArgs& base, uint32_t nitems, uint32_t nreduces, uint64_t nnz, hipStream_t st) {
