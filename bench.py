@@ -476,6 +476,11 @@ def main() -> None:
         "ccd_scatter_u_pass": 12.0 * Z + flags + 16.0 * n + 8.0 * m + 8.0 * m,
         "ccd_scatter_sweep": 8.0 * Z + flags + 4.0 * max(m, n) + 8.0 * min(m, n),
     }
+    if a.variant == -1 and os.environ.get("MFX_REF_FUSED", "1") != "0":
+        # (r4) the mode's launches are owner passes on the default schedule: per rank two fused passes (the fused passes' contract,
+        # mean of the two copies) and 2 (T - 1) read-only sweeps
+        fused = 12.0 * Z + 12.0 * (m + n) + 8.0 * (m + n)
+        alg["ccd_ref_order_sweep"] = (fused + (a.inner - 1) * alg["ccd_ref_order_sweep"]) / a.inner
     # bytes the LDS-panel kernels physically stream per non-zero: 16-bit local index + fp32 value read
     # + fp32 value written (the contract figure above keeps SURVEY 8d's 32-bit index)
     phys = {"ccd_fused_csc_pass": 10.0 * Z + 2 * flags, "ccd_fused_csr_pass": 10.0 * Z + 2 * flags,

@@ -297,10 +297,18 @@ int mfx_rank_one_sweep(int64_t nseg, int64_t nnz, const uint32_t* ptr, const uin
         FinalizeArgs f; f.lambda = lambda; f.out_vec = dout.get();
         if (variant == -1) {  // the reference's summation order: sums and division in one kernel (ccd_reforder.hip)
             std::vector<uint32_t> order;
-            const uint32_t nlong = ref_sweep_order(ptr, (uint32_t) nseg, &order);
+            const char* e_fused = std::getenv("MFX_REF_FUSED");
+            const bool old_form = e_fused && std::atoi(e_fused) == 0;  // (A/B: the r3 / early-r4 kernels)
+            const uint32_t nlong = ref_sweep_order(ptr, (uint32_t) nseg, &order, !old_form);
             DevBuf<uint32_t> dorder;
             MFX_TRY(dorder.alloc(order.size())); MFX_TRY(dorder.upload(order.data(), order.size(), MFX_HOST, cx.st));
-            MFX_TRY(launch_sweep_ref(s.view, dorder.get(), nlong, dvec.get(), lambda, dout.get(), cx.st));
+            if (old_form) {
+                MFX_TRY(launch_sweep_ref(s.view, dorder.get(), nlong, dvec.get(), lambda, dout.get(), cx.st));
+            } else {
+                RefStreams rs;
+                rs.main = cx.st;  // (one stream: the long segments' kernel first, the others behind it)
+                MFX_TRY(launch_ref_owner(FM_SWEEP, s.view, dorder.get(), nlong, dvec.get(), nullptr, f, rs));
+            }
             MFX_HIP(hipMemcpyAsync(out, dout.get(), sizeof(float) * nseg, hipMemcpyDeviceToHost, cx.st));
             MFX_HIP(hipStreamSynchronize(cx.st));
             return MFX_OK;

@@ -120,7 +120,8 @@ int launch_resid_wave(const SegStreamDev& s, const float* gathered, const float*
 // order: dispatch order of the segments (ref_sweep_order: longest first) or nullptr (ascending).
 // nlong: the leading `order` entries that take the two-wave plain-add form (ref_sweep_order's return value; 0 with order == nullptr)
 int launch_sweep_ref(const SegStreamDev& s, const uint32_t* order, uint32_t nlong, const float* vec, float lambda, float* out, hipStream_t st);
-uint32_t ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<uint32_t>* order);
+// owner_form: the count of long segments for launch_ref_owner (>= 4096 entries) instead of launch_sweep_ref's (>= 32768)
+uint32_t ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<uint32_t>* order, bool owner_form = false);
 
 // partials + carries of a flat pass -> dense gh[0..nseg) = g, gh[nseg..2nseg) = h (0 for empty).
 int launch_combine_dense(const SegStreamDev& s, float* gh, hipStream_t st);
@@ -149,6 +150,17 @@ struct FinalizeArgs {
     bool pack4_as3 = false;             // ... stored as 12-byte triples in the same buffer (scatter u-pass: the streamed operand's line fills are what bounds it)
 };
 int launch_finalize(const SegStreamDev& s, const FinalizeArgs& a, hipStream_t st);
+// (r4) Reference-order OWNER pass (ccd_reforder.hip): launch_seg_owner's contract -- pass + division + operand packs in one launch, FM_FCSC /
+// FM_FCSR (perseg must be f.pack2) or the read-only FM_SWEEP -- with every sum in the reference's order and the division g / h from
+// h = lambda * count + ... (src/CCD.cpp:6-16): bit for bit the reference's values.  order / nlong: ref_sweep_order's.  Items holding a
+// long segment run as a second kernel on rs.side when it is set (joined into rs.main before returning), else behind each other on rs.main.
+struct RefStreams {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+int launch_ref_owner(FlatMode mode, const SegStreamDev& s, const uint32_t* order, uint32_t nlong, const void* gather, const void* perseg,
+                     const FinalizeArgs& f, const RefStreams& rs);
+
 // calrmse_r1 (src/tools.cpp:261-270): resid[q] -= Wt[row] * Ht[col] - oldWt[row] * oldHt[col]; *sum_out = sum resid^2
 // resid[q] = val[q] - sum_t W[t][row] * H[t][col] (fp32, rank order): where a rank trace starts from
 int launch_test_resid_init(int64_t nnz_test, const uint32_t* row, const uint32_t* col, const float* val, const float* W, const float* H,

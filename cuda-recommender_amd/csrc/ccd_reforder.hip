@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <numeric>
 
 namespace mfx {
@@ -158,8 +159,9 @@ __global__ __launch_bounds__(kRefBlock) void k_sweep_ref(uint32_t nseg, const ui
 // issue slots too: 0.64 of the lane-to-lane form, not the microbenchmark's 0.37); v-sweep of the Netflix shape 1.93 -> 1.32 ms.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRef2Block = 128;
-constexpr uint32_t kRefLong = 32768;           // entries from which a segment takes the two-wave plain-add form (MFX_REF_LONG overrides, A/B):
+constexpr uint32_t kRefLong = 32768;           // k_sweep_ref2 (the as-written sequence, MFX_REF_FUSED=0): entries from which a segment takes the two-wave plain-add form:
                                                // Netflix shape, v-sweep 1.32 ms with 32768 against 1.39-1.49 ms with 8192 ... 1 and 1.93 ms without
+constexpr uint32_t kRefSplit = 4096;           // launch_ref_owner: entries from which a segment goes to k_ref_split (MFX_REF_LONG overrides both, A/B)
 constexpr uint32_t kStage2 = 1024;             // entries per pipeline stage of k_sweep_ref2: 16 per lane (a stage's chain takes ~2 us:
                                                // two stages of loads in flight cover the memory latency; with 256-entry stages they did not)
 using f32x4r = __attribute__((ext_vector_type(4))) float;
@@ -267,16 +269,431 @@ __global__ __launch_bounds__(kRef2Block) void k_sweep_ref2(uint32_t nseg, uint32
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// (r4) QUAD-ROW CHAINS: four segments per wavefront, and the fused pass of the default schedule in the reference's summation order.
+//
+// tools/ubench_chain.hip, second half: with the running sum as the PLAIN operand and the term as the DPP operand,
+//     v_add_f32_dpp s, x, s row_newbcast:j          (lane j of every row of 16 lanes, to the whole row)
+// a dependent add issues every 5.75 clocks (4.63 for a plain VGPR term, 7.3 with ds_read_b128 broadcasts, 12.4 for the lane-to-lane
+// wave_shr:1 step), PROVIDED the two s_nop the compiler puts between DPP instructions that read a register the previous VALU
+// instruction wrote are left out -- the hardware's hazard concerns the DPP (permuted) operand, which here was loaded long before;
+// the sums of the microbenchmark are bit-identical with and without them.  Hence inline asm for the 64 adds of a chunk.
+// The form: every ROW of 16 lanes carries its own segment's running sums (all 16 lanes the same value, redundantly); lane j of a
+// row holds entries 4 j ... 4 j + 3 of the row's current 64-entry chunk (ONE 16-byte load each of indices and values per lane and
+// chunk, like k_seg_owner), and the 64 adds of a chunk walk j = 0 ... 15, e = 0 ... 3: entry order.  A wavefront advances FOUR
+// independent chains per instruction where the lane-to-lane form advanced one -- rows of 200 entries (the u-sweep) cost a quarter
+// of the vector instructions -- and there is no LDS traffic in the chain at all.  Terms outside [lo, hi) are +0: s + 0 == s bit
+// for bit (a sum that started at +0 or lambda * count >= 0 is never -0), so chunks are aligned to 16 bytes and rows of different
+// lengths share a wave without masks in the chain.
+//
+// On top of it the reference-order mode gets the SCHEDULE of the default path (ccd_solver.hip, rank_fused_owner): the pending
+// subtraction of rank t - 1, the add-back of rank t and the first sweep of rank t in one pass per copy -- r' = (r - a b) + c d with
+// the reference's own unfused roundings (the element update of every other path), the term from r' -- and the division and the
+// operand packs of the next pass written by the segment's owner: two launches per rank instead of four sweeps / passes, no separate
+// residual pass (128 x 0.57 ms per outer iteration at the Netflix shape).  Every stored residual, every sum and every factor
+// entry keeps the reference's bits (tests/test_gpu_ccd_reforder.py, test_gpu_fullsize.py: unchanged).
+//
+// Two kernels per launch_ref_owner:
+//   k_ref_quad   one wavefront per item (4 segments, longest first), both chains (g, h) interleaved: issue-bound; loads two chunks
+//                ahead, the gather one chunk ahead, many waves per SIMD.  A throughput form: a wave's own progress on a long segment is
+//                one memory round trip per chunk (a 150 000-entry column takes it 2 ms).
+//   k_ref_split  items whose longest segment has >= kRefSplit = 4096 entries: a 512-thread workgroup per item.  Wave 0 runs the four g
+//                chains and wave 1 the four h chains -- ONE dependent add per entry and nothing else: their terms come from LDS, 64
+//                per ds_read_b128, put there a batch of 36 chunks ahead by the six loader waves (loads, gather, element update,
+//                write-back of r', products), one LDS-only barrier per batch.  What it took to make the chains the bound
+//                (237 k-entry column of the Netflix shape: 705 us per pass = 6.3 clocks per entry; tools/exp_ref_owner.sh,
+//                profiles/r04_exp_reforder_owner.txt):
+//                  * loaders that never wait for a load younger than a batch (explicit s_waitcnt: the compiler's counters, made
+//                    conservative by the conditional stores between a load and its use, waited for the loads just issued), and a
+//                    barrier that does not drain vmcnt (__syncthreads does): 1187 -> ~960 us, and no further --
+//                  * because k_ref_quad's waves on the SAME CU queue their gathers in front of the loaders' (with 1 quad workgroup per
+//                    2 CUs the split kernel took 705 us, with 2 per CU 1010 us; s_setprio changes nothing, it is the memory
+//                    pipeline of the CU).  A split workgroup therefore takes its CU for itself: 8 waves x 256 registers = the CU's
+//                    register file (the `asm volatile("" ::: "v255")`), and it is launched FIRST, on the main stream, with k_ref_quad
+//                    behind it on the side stream, so that its workgroups are placed before the first quad wave.
+//                  * with that, the split form is also the efficient one for every segment that keeps a CU busy (a CU serves four
+//                    chains at full speed): the threshold went from 32768 to 4096 entries (sweep: 147 ms per outer iteration at
+//                    16384, 115 at 8192, 95 at 4096, 99 at 2048, 95.5 at 1024; 120 / 143 / 177 ms at 65536 / 100 000 / 150 000).
+// Netflix shape, k = 64: v-pass 0.72 ms (the 237 k-entry chain), u-pass 0.72 ms (k_ref_quad, bound by the L2 gather like the plain flat
+// pass), the mode 201 -> 95 ms per outer iteration (profiles/r04_bench_reforder.json).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+using u32x4r = __attribute__((ext_vector_type(4))) uint32_t;
+
+struct RefOwnerArgs {
+    const uint32_t* ptr;      // [nseg + 1] input-order pointers (plain layout)
+    const uint32_t* idx;
+    float* val;
+    const void* gather;
+    const void* perseg;
+    const uint32_t* order;    // [nseg] segments, longest first
+    uint32_t nseg;
+    uint32_t item0, nitems;   // k_ref_quad: items [item0, nitems); k_ref_split: item = blockIdx.x (< item0)
+    float lambda;
+    float* out_vec;
+    float2* pack2;            // in: (prev_new, cur_old) = perseg; out: (cur_new, next_old)
+    const float* next_vec;
+    float4* pack4;            // out: (prev_new, cur_old, cur_new, 0), may be nullptr
+};
+
+template <int MODE> struct RefTraits;
+template <> struct RefTraits<FM_SWEEP> { using G = float;  using P = float;  static constexpr bool kWrite = false, kPerSeg = false; };
+template <> struct RefTraits<FM_FCSC>  { using G = float2; using P = float2; static constexpr bool kWrite = true,  kPerSeg = true; };
+template <> struct RefTraits<FM_FCSR>  { using G = float4; using P = float2; static constexpr bool kWrite = true,  kPerSeg = true; };
+
+// One element: the new residual value (the reference's unfused update, src/CCD.cpp:25,36 -- element_op of ccd_kernels.hip) and the
+// operand of its two products.
+template <int MODE>
+__device__ __forceinline__ void ref_element(float v, const typename RefTraits<MODE>::G& ga, const typename RefTraits<MODE>::P& ps,
+                                            float& v_out, float& op) {
+    if constexpr (MODE == FM_SWEEP) {
+        v_out = v; op = ga;
+    } else if constexpr (MODE == FM_FCSC) {
+        v_out = add_rn(sub_rn(v, mul_rn(ga.x, ps.x)), mul_rn(ga.y, ps.y)); op = ga.y;
+    } else {
+        v_out = add_rn(sub_rn(v, mul_rn(ga.x, ps.x)), mul_rn(ga.y, ps.y)); op = ga.z;
+    }
+}
+
+// 64 dependent adds: s <- s + x[e] of lane j of the row, j = 0 ... 15, e = 0 ... 3 (see above for the missing s_nops)
+#define MFX_BC1(S, X, J) "v_add_f32_dpp " S ", " X ", " S " row_newbcast:" #J " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define MFX_BC4(J) MFX_BC1("%0", "%1", J) MFX_BC1("%0", "%2", J) MFX_BC1("%0", "%3", J) MFX_BC1("%0", "%4", J)
+#define MFX_BC8(J) MFX_BC1("%0", "%2", J) MFX_BC1("%1", "%6", J) MFX_BC1("%0", "%3", J) MFX_BC1("%1", "%7", J) \
+                   MFX_BC1("%0", "%4", J) MFX_BC1("%1", "%8", J) MFX_BC1("%0", "%5", J) MFX_BC1("%1", "%9", J)
+#define MFX_ALL16(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+__device__ __forceinline__ void chain_one(float& s, const f32x4r& x) {
+    asm volatile("s_nop 1\n" MFX_ALL16(MFX_BC4) : "+v"(s) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+}
+__device__ __forceinline__ void chain_two(float& sg, float& sh, const f32x4r& xg, const f32x4r& xh) {
+    asm volatile("s_nop 1\n" MFX_ALL16(MFX_BC8)
+                 : "+v"(sg), "+v"(sh)
+                 : "v"(xg[0]), "v"(xg[1]), "v"(xg[2]), "v"(xg[3]), "v"(xh[0]), "v"(xh[1]), "v"(xh[2]), "v"(xh[3]));
+}
+
+// The segment of this lane's row: item q holds the segments order[4 q ... 4 q + 3].
+struct RowSeg {
+    uint32_t c, lo, hi, b0, nch;  // b0: first chunk's first entry (lo rounded down to 16 bytes); nch: 64-entry chunks
+    bool have;
+};
+__device__ __forceinline__ RowSeg row_segment(const RefOwnerArgs& a, uint32_t item, uint32_t lane) {
+    RowSeg r;
+    const uint32_t q = 4u * item + (lane >> 4);
+    r.have = q < a.nseg;
+    r.c = r.have ? a.order[q] : 0u;
+    r.lo = r.have ? a.ptr[r.c] : 0u;
+    r.hi = r.have ? a.ptr[r.c + 1] : 0u;
+    r.b0 = r.lo & ~3u;
+    r.nch = r.hi > r.lo ? (r.hi - r.b0 + 63u) / 64u : 0u;
+    return r;
+}
+__device__ __forceinline__ uint32_t rows_max(uint32_t x) {  // wave-uniform maximum over the four rows
+    const uint32_t a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16), c = __builtin_amdgcn_readlane(x, 32),
+                   d = __builtin_amdgcn_readlane(x, 48);
+    return max(max(a, b), max(c, d));
+}
+// quad of chunk t: first entry, and where to load it from (a quad with no entry of the segment re-reads entries 0 ... 3: every
+// store holds at least one padded tile)
+__device__ __forceinline__ uint32_t quad_pos(const RowSeg& r, uint32_t t, uint32_t lane) { return r.b0 + 64u * t + 4u * (lane & 15u); }
+__device__ __forceinline__ uint32_t quad_at(const RowSeg& r, uint32_t p) { return p < r.hi ? p : 0u; }
+
+template <int MODE>
+__device__ __forceinline__ void gather_quad(const RefOwnerArgs& a, const RowSeg& r, uint32_t p, const u32x4r& id,
+                                            typename RefTraits<MODE>::G (&g)[4]) {
+    using G = typename RefTraits<MODE>::G;
+    const G* __restrict__ gather = static_cast<const G*>(a.gather);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t pos = p + (uint32_t) e;
+        g[e] = gather[(pos >= r.lo && pos < r.hi) ? id[e] : 0u];  // (padding and the neighbours' entries: not this gather's indices)
+    }
+}
+// element update + write-back of a quad; the two products of every entry of [lo, hi), +0 elsewhere
+template <int MODE, bool STORE, bool WANT_G, bool WANT_H>
+__device__ __forceinline__ void quad_terms(const RefOwnerArgs& a, const RowSeg& r, uint32_t p, const f32x4r& v,
+                                           const typename RefTraits<MODE>::G (&g)[4], const typename RefTraits<MODE>::P& ps,
+                                           f32x4r& xg, f32x4r& xh) {
+    f32x4r o;
+    bool all_live = true;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t pos = p + (uint32_t) e;
+        const bool live = pos >= r.lo && pos < r.hi;
+        all_live &= live;
+        float vo, op;
+        ref_element<MODE>(v[e], g[e], ps, vo, op);
+        o[e] = vo;
+        if constexpr (WANT_G) xg[e] = live ? mul_rn(op, vo) : 0.f;
+        if constexpr (WANT_H) xh[e] = live ? mul_rn(op, op) : 0.f;
+    }
+    if constexpr (STORE && RefTraits<MODE>::kWrite) {
+        if (all_live) {
+            *reinterpret_cast<f32x4r*>(a.val + p) = o;
+        } else if (p < r.hi) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const uint32_t pos = p + (uint32_t) e; if (pos >= r.lo && pos < r.hi) a.val[pos] = o[e]; }
+        }
+    }
+}
+// the owner's last step: the reference's division (g / h with h started at lambda * count; 0 for an empty segment, src/CCD.cpp:6-16)
+// and the operand packs of the next passes (seg_owner_finish of ccd_kernels.hip)
+template <int MODE>
+__device__ __forceinline__ void ref_finish(const RefOwnerArgs& a, const RowSeg& r, float g, float h, const typename RefTraits<MODE>::P& ps, float next_old) {
+    const float x = r.hi > r.lo ? g / h : 0.f;  // correctly rounded fp32 division, as on the host
+    a.out_vec[r.c] = x;
+    if constexpr (MODE != FM_SWEEP) {
+        if (a.pack4) a.pack4[r.c] = make_float4(ps.x, ps.y, x, 0.f);
+        a.pack2[r.c] = make_float2(x, a.next_vec == a.out_vec ? x : next_old);
+    }
+}
+
+constexpr int kQuadBlock = 128;
+template <int MODE>
+__global__ __launch_bounds__(kQuadBlock) void k_ref_quad(RefOwnerArgs a) {
+    using TR = RefTraits<MODE>;
+    using G = typename TR::G;
+    using P = typename TR::P;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * kQuadBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kQuadBlock) >> 6;
+    for (uint32_t item = a.item0 + wave; item < a.nitems; item += nwaves) {
+        const RowSeg r = row_segment(a, item, lane);
+        P ps{};
+        if constexpr (TR::kPerSeg) { if (r.have) ps = static_cast<const P*>(a.perseg)[r.c]; }
+        float next_old = 0.f;
+        if constexpr (MODE != FM_SWEEP) { if (r.have && a.next_vec) next_old = a.next_vec[r.c]; }
+        float sg = 0.f, sh = mul_rn(a.lambda, (float) (r.hi - r.lo));  // float * unsigned (src/CCD.cpp:112,120)
+        const uint32_t nmax = rows_max(r.nch);
+        if (nmax) {
+            // in flight: the indices of chunk t + 2, the values and the gather of chunk t + 1, the chains of chunk t.  Two register
+            // sets that swap roles every chunk (the loop is unrolled by two: no copies).
+            u32x4r ia, ib;
+            f32x4r va, vb;
+            G ga[4], gb[4];
+            uint32_t pa = quad_pos(r, 0, lane), pb = quad_pos(r, 1, lane);
+            ia = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, pa));
+            va = *reinterpret_cast<const f32x4r*>(a.val + quad_at(r, pa));
+            ib = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, pb));
+            gather_quad<MODE>(a, r, pa, ia, ga);
+            // step: chunk t sits in (v_cur, g_cur), the indices of chunk t + 1 in i_next; i_cur (consumed) takes chunk t + 2's
+            auto step = [&](uint32_t t, uint32_t p_cur, uint32_t& p_next, u32x4r& i_cur, const u32x4r& i_next, const f32x4r& v_cur, f32x4r& v_next,
+                            const G (&g_cur)[4], G (&g_next)[4]) {
+                p_next = quad_pos(r, t + 1, lane);
+                v_next = *reinterpret_cast<const f32x4r*>(a.val + quad_at(r, p_next));
+                gather_quad<MODE>(a, r, p_next, i_next, g_next);
+                i_cur = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, quad_pos(r, t + 2, lane)));
+                f32x4r xg, xh;
+                quad_terms<MODE, true, true, true>(a, r, p_cur, v_cur, g_cur, ps, xg, xh);
+                chain_two(sg, sh, xg, xh);
+            };
+            for (uint32_t t = 0; t < nmax; t += 2) {
+                step(t, pa, pb, ia, ib, va, vb, ga, gb);
+                if (t + 1 >= nmax) break;
+                step(t + 1, pb, pa, ib, ia, vb, va, gb, ga);
+            }
+        }
+        if (r.have && (lane & 15u) == 0) ref_finish<MODE>(a, r, sg, sh, ps, next_old);
+    }
+}
+
+constexpr int kSplitLoaders = 6;                           // loader waves of a split workgroup (waves 2 ... 7): eight waves = two per SIMD,
+constexpr int kSplitBlock = 64 * (2 + kSplitLoaders);      // 256 registers each (at ten waves the allocator moved in-flight gathers about)
+constexpr uint32_t kSplitBatchMax = 36;                    // chunks per batch: 6 per loader wave (4 with 16-byte gather operands)
+constexpr uint32_t kSplitChunkFloats = 2 * 256;            // a chunk's terms: g of the four rows, then h
+constexpr size_t kSplitLds = (size_t) 2 * kSplitBatchMax * kSplitChunkFloats * sizeof(float) + 16;  // two batches + the four g results
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence drains
+// EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)) -- including the loads a loader wave has issued for the batches
+// to come, i.e. one fully exposed memory round trip per batch.  The waves of a split workgroup exchange data through LDS alone.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int MODE>
+__global__ __launch_bounds__(kSplitBlock) void k_ref_split(RefOwnerArgs a) {
+    using TR = RefTraits<MODE>;
+    using G = typename TR::G;
+    using P = typename TR::P;
+    extern __shared__ __attribute__((aligned(16))) float split_lds[];
+    float* g_slot = split_lds + 2 * kSplitBatchMax * kSplitChunkFloats;
+    constexpr int LG = sizeof(G) > 8 ? 4 : 6;              // chunks per loader wave and batch
+    constexpr uint32_t kSplitBatch = LG * kSplitLoaders;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RowSeg r = row_segment(a, blockIdx.x, lane);
+    P ps{};
+    if constexpr (TR::kPerSeg) { if (r.have) ps = static_cast<const P*>(a.perseg)[r.c]; }
+    const uint32_t nmax = rows_max(r.nch);
+    const uint32_t nbatch = (nmax + kSplitBatch - 1) / kSplitBatch;
+    // Loader wave w (= wave - 2) owns the chunks t = w (mod kSplitLoaders) of every batch: kSplitGroup chunks, handled together.
+    // Nothing a loader waits for was issued less than a batch (the chains' ~5 us) earlier: while it does the arithmetic of batch n,
+    // the gathers of batch n + 1 and the index / value loads of batches n + 2 / n + 1 are in flight (two register sets that swap
+    // roles every batch -- the batch loop is unrolled by two, there are no copies of registers a load is still to write).  Under
+    // k_ref_quad's traffic a round trip takes ~3.4 us: a first version that waited for the loads, then for the gathers, twice per
+    // batch, took 1187 us for the 237 k-entry column (the r3 kernel's time), one exposed round trip per batch 850-920 us.
+    u32x4r id[LG];
+    f32x4r va[LG], vb[LG];
+    G ga[LG][4], gb[LG][4];
+    auto chunk_of = [&](uint32_t n, int u) { return n * kSplitBatch + (uint32_t) u * kSplitLoaders + (wave - 2u); };
+    auto load_idx = [&](uint32_t n) {
+#pragma unroll
+        for (int u = 0; u < LG; ++u) {
+            const uint32_t t = chunk_of(n, u), p = quad_pos(r, t, lane);
+            id[u] = *reinterpret_cast<const u32x4r*>(a.idx + (t < nmax ? quad_at(r, p) : 0u));
+        }
+    };
+    auto load_val = [&](uint32_t n, f32x4r (&v)[LG]) {
+#pragma unroll
+        for (int u = 0; u < LG; ++u) {
+            const uint32_t t = chunk_of(n, u), p = quad_pos(r, t, lane);
+            v[u] = *reinterpret_cast<const f32x4r*>(a.val + (t < nmax ? quad_at(r, p) : 0u));
+        }
+    };
+    auto gather_batch = [&](uint32_t n, G (&g)[LG][4]) {  // from id = the indices of batch n
+#pragma unroll
+        for (int u = 0; u < LG; ++u) {
+            const uint32_t t = chunk_of(n, u);
+            RowSeg rr = r;
+            if (t >= nmax) rr.hi = rr.lo;  // (a chunk past the end: nothing is live, nothing is gathered or stored)
+            gather_quad<MODE>(a, rr, quad_pos(r, t, lane), id[u], g[u]);
+        }
+    };
+    // the terms of batch n into buffer n & 1; on entry (v_cur, g_cur) belong to batch n and id holds the indices of batch n + 1
+    auto produce = [&](uint32_t n, const f32x4r (&v_cur)[LG], f32x4r (&v_next)[LG], const G (&g_cur)[LG][4], G (&g_next)[LG][4]) {
+        // ONE wait, for everything the previous batch issued (a batch-time ago), then all of this batch's loads, then the arithmetic.
+        // Left to the compiler's counters the arithmetic waited for loads issued a few instructions earlier: its model allows for the
+        // conditional stores (and, in a first version, conditional loads) between a load and its use NOT having been issued, so
+        // every vmcnt it derives is too strict by that many -- one exposed round trip per batch, the very thing the pipeline removes.
+        // Loads of batches past the end re-read entries 0 ... 3 (unconditional: same reason).
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        gather_batch(n + 1, g_next);
+        load_val(n + 1, v_next);
+        load_idx(n + 2);
+#pragma unroll
+        for (int u = 0; u < LG; ++u) {
+            const uint32_t t = chunk_of(n, u);
+            if (t < nmax) {
+                f32x4r xg, xh;
+                quad_terms<MODE, true, true, true>(a, r, quad_pos(r, t, lane), v_cur[u], g_cur[u], ps, xg, xh);
+                float* dst = split_lds + ((n & 1u) * kSplitBatch + (t - n * kSplitBatch)) * kSplitChunkFloats + 4u * lane;
+                *reinterpret_cast<f32x4r*>(dst) = xg;
+                *reinterpret_cast<f32x4r*>(dst + 256) = xh;
+            }
+        }
+    };
+    auto consume = [&](uint32_t b, float& s) {
+        const uint32_t cnt = min(kSplitBatch, nmax - b * kSplitBatch);
+        const float* src = split_lds + (b & 1u) * kSplitBatch * kSplitChunkFloats + wave * 256u + 4u * lane;
+        f32x4r x = *reinterpret_cast<const f32x4r*>(src);
+        for (uint32_t c = 0; c < cnt; ++c) {
+            const f32x4r xn = *reinterpret_cast<const f32x4r*>(src + min(c + 1, cnt - 1) * kSplitChunkFloats);
+            chain_one(s, x);
+            x = xn;
+        }
+    };
+    float s = wave == 0 ? 0.f : mul_rn(a.lambda, (float) (r.hi - r.lo));  // wave 0: g, wave 1: h (float * unsigned, src/CCD.cpp:112,120)
+    const bool loader = wave >= 2;
+    asm volatile("" ::: "v255");  // (256 registers per wave: see above -- the workgroup's eight waves fill the CU's register file)
+    if (loader && nbatch) {
+        load_idx(0);
+        load_val(0, va);
+        gather_batch(0, ga);
+        load_idx(1);
+        produce(0, va, vb, ga, gb);
+    }
+    lds_barrier();
+    for (uint32_t b = 0; b < nbatch; b += 2) {
+        // even batch b is consumed while the loaders make batch b + 1 (its inputs in the b sets), then the other way round
+        if (wave < 2) consume(b, s);
+        else if (loader && b + 1 < nbatch) produce(b + 1, vb, va, gb, ga);
+        lds_barrier();
+        if (b + 1 >= nbatch) break;
+        if (wave < 2) consume(b + 1, s);
+        else if (loader && b + 2 < nbatch) produce(b + 2, va, vb, ga, gb);
+        lds_barrier();
+    }
+    if (wave == 0 && (lane & 15u) == 0) g_slot[lane >> 4] = s;
+    lds_barrier();
+    if (wave == 1 && r.have && (lane & 15u) == 0) {
+        float next_old = 0.f;
+        if constexpr (MODE != FM_SWEEP) { if (a.next_vec) next_old = a.next_vec[r.c]; }
+        ref_finish<MODE>(a, r, g_slot[lane >> 4], s, ps, next_old);
+    }
+}
+
 }  // namespace
 
+// Items (four segments of `order` each) that take the split form: those holding one of the nlong long segments.
+uint32_t ref_split_items(uint32_t nlong) { return (nlong + 3u) / 4u; }
+
+int launch_ref_owner(FlatMode mode, const SegStreamDev& s, const uint32_t* order, uint32_t nlong, const void* gather, const void* perseg,
+                     const FinalizeArgs& f, const RefStreams& rs) {
+    if (s.nseg == 0) return MFX_OK;
+    MFX_REQUIRE(s.panel_rows == 0 && !s.scatter && s.ptr && s.idx && s.val && order, "launch_ref_owner: needs the plain layout and the dispatch order");
+    MFX_REQUIRE(!f.gh_dense && !f.cnt_override && !f.pack4_as3 && !f.nmf && !f.fundec_seg && f.out_vec, "launch_ref_owner: dense / overridden / extended finalize inputs are not supported");
+    MFX_REQUIRE(mode == FM_SWEEP || ((mode == FM_FCSC || mode == FM_FCSR) && f.pack2 && f.next_vec && f.pack2 == perseg), "launch_ref_owner: bad mode / packs");
+    RefOwnerArgs a;
+    a.ptr = s.ptr; a.idx = s.idx; a.val = s.val; a.gather = gather; a.perseg = perseg; a.order = order; a.nseg = s.nseg;
+    a.nitems = (s.nseg + 3u) / 4u;
+    a.item0 = std::min(ref_split_items(nlong), a.nitems);
+    a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
+    const bool side = a.item0 > 0 && rs.side && rs.fork && rs.join && a.item0 < a.nitems;
+    // the split kernel goes FIRST, on the main stream; the quad kernel follows on the side stream (behind an event recorded after the
+    // split launch is enqueued, not after it completes)
+    hipStream_t st_split = rs.main, st_quad = side ? rs.side : rs.main;
+    if (a.item0 > 0) {
+        static std::mutex m;
+        static bool attr_set[3][64] = {};
+        int dev = 0;
+        MFX_HIP(hipGetDevice(&dev));
+        const int mi = mode == FM_SWEEP ? 0 : (mode == FM_FCSC ? 1 : 2);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (dev < 0 || dev >= 64 || !attr_set[mi][dev]) {
+                const void* fn = mode == FM_SWEEP ? reinterpret_cast<const void*>(k_ref_split<FM_SWEEP>)
+                                 : mode == FM_FCSC ? reinterpret_cast<const void*>(k_ref_split<FM_FCSC>) : reinterpret_cast<const void*>(k_ref_split<FM_FCSR>);
+                MFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSplitLds));
+                if (dev >= 0 && dev < 64) attr_set[mi][dev] = true;
+            }
+        }
+        if (side) {
+            MFX_HIP(hipEventRecord(rs.fork, rs.main));
+            MFX_HIP(hipStreamWaitEvent(rs.side, rs.fork, 0));
+        }
+        switch (mode) {
+            case FM_SWEEP: hipLaunchKernelGGL(k_ref_split<FM_SWEEP>, dim3(a.item0), dim3(kSplitBlock), kSplitLds, st_split, a); break;
+            case FM_FCSC: hipLaunchKernelGGL(k_ref_split<FM_FCSC>, dim3(a.item0), dim3(kSplitBlock), kSplitLds, st_split, a); break;
+            default: hipLaunchKernelGGL(k_ref_split<FM_FCSR>, dim3(a.item0), dim3(kSplitBlock), kSplitLds, st_split, a); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MFX_ERR_HIP, "k_ref_split launch failed: %s", hipGetErrorString(e));
+    }
+    if (a.item0 < a.nitems) {
+        const uint32_t waves_per_block = kQuadBlock / 64, nq = a.nitems - a.item0;
+        static const uint32_t cap = [] { const char* e = std::getenv("MFX_REF_QUAD_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t) v : 256u * 16u; }();
+        const uint32_t grid = std::min<uint32_t>((nq + waves_per_block - 1) / waves_per_block, cap);
+        switch (mode) {
+            case FM_SWEEP: hipLaunchKernelGGL(k_ref_quad<FM_SWEEP>, dim3(grid), dim3(kQuadBlock), 0, st_quad, a); break;
+            case FM_FCSC: hipLaunchKernelGGL(k_ref_quad<FM_FCSC>, dim3(grid), dim3(kQuadBlock), 0, st_quad, a); break;
+            default: hipLaunchKernelGGL(k_ref_quad<FM_FCSR>, dim3(grid), dim3(kQuadBlock), 0, st_quad, a); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MFX_ERR_HIP, "k_ref_quad launch failed: %s", hipGetErrorString(e));
+    }
+    if (side) {
+        MFX_HIP(hipEventRecord(rs.join, rs.side));
+        MFX_HIP(hipStreamWaitEvent(rs.main, rs.join, 0));
+    }
+    return MFX_OK;
+}
+
 // Segments by descending length (ties: ascending id): the dispatch order of k_sweep_ref.
-uint32_t ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<uint32_t>* order) {
+uint32_t ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<uint32_t>* order, bool owner_form) {
     order->resize(nseg);
     std::iota(order->begin(), order->end(), 0u);
     std::stable_sort(order->begin(), order->end(), [&](uint32_t x, uint32_t y) {
         return ptr_host[x + 1] - ptr_host[x] > ptr_host[y + 1] - ptr_host[y];
     });
-    static const uint32_t thr = [] { const char* e = std::getenv("MFX_REF_LONG"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t) v : kRefLong; }();
+    static const uint32_t env_thr = [] { const char* e = std::getenv("MFX_REF_LONG"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t) v : 0u; }();
+    const uint32_t thr = env_thr ? env_thr : (owner_form ? kRefSplit : kRefLong);
     uint32_t nlong = 0;
     while (nlong < nseg && nlong < 8192u && ptr_host[(*order)[nlong] + 1] - ptr_host[(*order)[nlong]] >= thr) ++nlong;
     return nlong;

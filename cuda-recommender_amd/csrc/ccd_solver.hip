@@ -648,6 +648,12 @@ CcdSolver::~CcdSolver() {
         (void) hipStreamSynchronize(st2_);
         (void) hipStreamDestroy(st2_);
     }
+    if (ref_streams_.side) {
+        (void) hipStreamSynchronize(ref_streams_.side);
+        (void) hipStreamDestroy(ref_streams_.side);
+    }
+    if (ref_streams_.fork) (void) hipEventDestroy(ref_streams_.fork);
+    if (ref_streams_.join) (void) hipEventDestroy(ref_streams_.join);
     if (st_) {
         (void) hipStreamSynchronize(st_);
         (void) hipStreamDestroy(st_);
@@ -737,16 +743,25 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
         MFX_HIP(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     }
     if (ref_order_) {  // dispatch order of the reference-order sweeps: longest segment first (ccd_reforder.hip)
+        const char* e = std::getenv("MFX_REF_FUSED");
+        ref_fused_ = !(e && std::atoi(e) == 0);
         for (int side = 0; side < 2; ++side) {
             const SegStreamDev& v = side == 0 ? csc_.view : csr_.view;
             std::vector<uint32_t> ptr_h((size_t) v.nseg + 1), order;
             MFX_HIP(hipMemcpyAsync(ptr_h.data(), v.ptr, sizeof(uint32_t) * ptr_h.size(), hipMemcpyDeviceToHost, st_));
             MFX_HIP(hipStreamSynchronize(st_));
-            (side == 0 ? ref_nlong_csc_ : ref_nlong_csr_) = ref_sweep_order(ptr_h.data(), v.nseg, &order);
+            (side == 0 ? ref_nlong_csc_ : ref_nlong_csr_) = ref_sweep_order(ptr_h.data(), v.nseg, &order, ref_fused_);
             DevBuf<uint32_t>& dst = side == 0 ? ref_order_csc_ : ref_order_csr_;
             MFX_TRY(dst.alloc(order.size()));
             MFX_TRY(dst.upload(order.data(), order.size(), MFX_HOST, st_));
             MFX_HIP(hipStreamSynchronize(st_));
+        }
+        if (ref_fused_) {
+            ref_streams_.main = st_;
+            MFX_HIP(hipStreamCreateWithFlags(&ref_streams_.side, hipStreamNonBlocking));
+            MFX_HIP(hipEventCreateWithFlags(&ref_streams_.fork, hipEventDisableTiming));
+            MFX_HIP(hipEventCreateWithFlags(&ref_streams_.join, hipEventDisableTiming));
+            MFX_TRY(ref_zero_cols_.alloc_zero(n_, st_));
         }
     }
 
@@ -1085,6 +1100,37 @@ int CcdSolver::rank_fused_owner(uint32_t t) {
     return MFX_OK;
 }
 
+// (r4) Reference-order mode on the schedule of rank_fused_owner: every sum in the reference's order (launch_ref_owner), the
+// element update the reference's own -- two launches per rank, no separate residual pass; bit for bit the as-written sequence.
+int CcdSolver::rank_ref_fused(uint32_t t, bool add_back) {
+    const uint32_t next = (t + 1) % k_;
+    // invariant on entry, as in rank_fused: packA = (u_prev_new | 0, W[t] old), packB = (v_prev_new | 0, H[t] old)
+    if (!add_back)  // first outer iteration: the reference does not add rank t back (src/CCD.cpp:100-104; H starts at 0, so the term
+                    // is u * 0 anyway) -- the column side's add-back operand reads 0 whatever H holds
+        PROF(KernelProfiler::K_PACK, launch_pack2(n_, pending_sub_ >= 0 ? Ht((uint32_t) pending_sub_) : nullptr, ref_zero_cols_.get(), packB_.get(), st_));
+    FinalizeArgs fv = fin_base();
+    fv.lambda = p_.lambda; fv.out_vec = Ht(t); fv.pack2 = packB_.get(); fv.next_vec = Ht(next); fv.pack4 = packC_.get();
+    PROF(KernelProfiler::K_SWEEP_REF, launch_ref_owner(FM_FCSC, csc_.view, ref_order_csc_.get(), ref_nlong_csc_, packA_.get(), packB_.get(), fv, ref_streams_));
+    FinalizeArgs fu = fin_base();
+    fu.lambda = p_.lambda; fu.out_vec = Wt(t); fu.pack2 = packA_.get(); fu.next_vec = Wt(next);
+    PROF(KernelProfiler::K_SWEEP_REF, launch_ref_owner(FM_FCSR, csr_.view, ref_order_csr_.get(), ref_nlong_csr_, packC_.get(), packA_.get(), fu, ref_streams_));
+    bool stop = false;
+    MFX_TRY(inner_stop(t, 1, &stop));
+    for (int it = 2; it <= p_.maxinneriter && !stop; ++it) {  // remaining inner iterations: read-only sweeps
+        FinalizeArgs f2 = fin_base(); f2.out_vec = Ht(t);
+        PROF(KernelProfiler::K_SWEEP_REF, launch_ref_owner(FM_SWEEP, csc_.view, ref_order_csc_.get(), ref_nlong_csc_, Wt(t), nullptr, f2, ref_streams_));
+        FinalizeArgs f3 = fin_base(); f3.out_vec = Wt(t);
+        PROF(KernelProfiler::K_SWEEP_REF, launch_ref_owner(FM_SWEEP, csr_.view, ref_order_csr_.get(), ref_nlong_csr_, Ht(t), nullptr, f3, ref_streams_));
+        MFX_TRY(inner_stop(t, it, &stop));
+    }
+    if (p_.maxinneriter > 1) {  // the packs must carry the FINAL (u_t, v_t)
+        PROF(KernelProfiler::K_PACK, launch_pack2(m_, Wt(t), Wt(next), packA_.get(), st_));
+        PROF(KernelProfiler::K_PACK, launch_pack2(n_, Ht(t), Ht(next), packB_.get(), st_));
+    }
+    pending_sub_ = (int32_t) t;
+    return MFX_OK;
+}
+
 int CcdSolver::rank_fused(uint32_t t) {
     if (scatter_) return rank_fused_scatter(t);
     if (owner_mode_) return rank_fused_owner(t);
@@ -1144,7 +1190,7 @@ int CcdSolver::flush_pending() {
     const uint32_t t = (uint32_t) pending_sub_, next = (t + 1) % k_;
     MFX_TRY(resid(csc_, Wt(t), Ht(t), 0));
     MFX_TRY(resid(csr_, Ht(t), Wt(t), 0));
-    if (ref_order_) { pending_sub_ = -1; return MFX_OK; }  // (the operand packs below belong to the fused schedule)
+    if (ref_order_ && !ref_fused_) { pending_sub_ = -1; return MFX_OK; }  // (the operand packs below belong to the fused schedules)
     PROF(KernelProfiler::K_PACK, launch_pack2(m_, nullptr, Wt(next), packA_.get(), st_));
     PROF(KernelProfiler::K_PACK, launch_pack2(n_, nullptr, Ht(next), packB_.get(), st_));
     pending_sub_ = -1;
@@ -1198,6 +1244,7 @@ int CcdSolver::resid(SegStreamStore& s, const float* gathered, const float* per_
 int CcdSolver::rank_as_written(uint32_t t, bool add_back) {
     float* u = Wt(t);
     float* v = Ht(t);
+    if (ref_order_ && ref_fused_) return rank_ref_fused(t, add_back);
     if (ref_order_) {
         // (r4) reference-order mode: the subtraction of rank t - 1 and the add-back of rank t are two consecutive elementwise passes
         // over the same copy (src/CCD.cpp:100-134) -- applied in ONE pass per copy, in the same order and with the same two roundings

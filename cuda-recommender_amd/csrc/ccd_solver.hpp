@@ -147,7 +147,14 @@ private:
     // kernel_variant = -1: sweeps in the reference's summation order (ccd_reforder.hip), bit-identical to src/CCD.cpp
     bool ref_order_ = false;
     DevBuf<uint32_t> ref_order_csc_, ref_order_csr_;  // segments, longest first
-    uint32_t ref_nlong_csc_ = 0, ref_nlong_csr_ = 0;  // ... of which this many take the two-wave plain-add form (ccd_reforder.hip)
+    uint32_t ref_nlong_csc_ = 0, ref_nlong_csr_ = 0;  // ... of which this many are long (>= 32768 entries: ccd_reforder.hip)
+    // (r4) the mode on the default path's schedule: subtraction of rank t - 1, add-back of rank t, first sweep and division in one
+    // reference-order owner pass per copy (launch_ref_owner), the long segments' workgroups on a second stream.  MFX_REF_FUSED=0: the
+    // as-written sequence (separate residual passes, k_sweep_ref / k_sweep_ref2), kept for A/B.
+    bool ref_fused_ = false;
+    RefStreams ref_streams_;
+    DevBuf<float> ref_zero_cols_;      // [n] zeros: the add-back operand of the first outer iteration (the reference skips that add-back)
+    int rank_ref_fused(uint32_t t, bool add_back);
     // slabs -> dense (g,h) -> [all-reduce] -> finalize, for one panel group of the streamed store (-1: all), on `st` (nullptr: st_)
     int scatter_finalize(bool cols, const FinalizeArgs& base, int group = -1, hipStream_t st = nullptr);
     // (r4) overlap of the column-side exchange with the column pass (sharded solve, scatter layout): see init()

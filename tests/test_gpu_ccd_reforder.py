@@ -175,3 +175,53 @@ def test_reference_order_mode_argument_checks(mfx):
     p.kernel_variant = -2
     with pytest.raises(mfx.MfxError, match="kernel_variant"):
         mfx.CcdSolver(d, mfx.test_data_of(d), p)
+
+
+# ---- (r4) the mode's two forms: the owner passes on the default path's schedule (k_ref_quad / k_ref_split: subtraction, add-back,
+# first sweep and division in one launch per copy) and the as-written sequence (MFX_REF_FUSED=0: one launch per reference kernel)
+
+def _solve(mfx, d, W0, k, lam, t, T):
+    s = mfx.CcdSolver(d, mfx.test_data_of(d), _params(mfx, k, lam, t, T))
+    s.set_factors(W0.copy())
+    rep = s.iterate(t)
+    W, H = s.get_factors()
+    csc, csr = s.get_residual(d.nnz)
+    s.close()
+    return W, H, csc, csr, np.array([r.rmse for r in rep])
+
+
+@pytest.mark.parametrize("T", [1, 3])
+def test_reference_order_owner_passes_equal_the_as_written_sequence(mfx, orc, monkeypatch, T):
+    """Same bits from both forms and from the oracle, on a matrix whose columns AND rows reach the split kernel
+    (segments of >= 4096 entries on both sides, next to thousands of short ones and empty ones)."""
+    d = mfx.dataset.synth_ratings(9000, 6000, 1_500_000, seed=21, skew=1.3, test_frac=0.01, empty_row_frac=0.01, empty_col_frac=0.01)
+    assert np.diff(d.csc_col_ptr).max() >= 4096 and np.diff(d.csr_row_ptr).max() >= 4096
+    k, lam, t = 6, 0.05, 2
+    W0 = mfx.initial_col(k, d.rows)
+    Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, T, orc.max_threads())
+    out = {}
+    for form in ("1", "0"):
+        monkeypatch.setenv("MFX_REF_FUSED", form)
+        out[form] = _solve(mfx, d, W0, k, lam, t, T)
+    for form, (W, H, csc, csr, rmse) in out.items():
+        assert np.array_equal(bits(W), bits(Wr)) and np.array_equal(bits(H), bits(Hr)), form
+        assert np.array_equal(bits(csc), bits(csc_ref)) and np.array_equal(bits(csr), bits(csr_ref)), form
+        assert np.all(np.abs(rmse - rmse_ref) < 1e-12), form
+
+
+def test_reference_order_sweep_op_both_forms(mfx, orc, monkeypatch):
+    """mfx_rank_one_sweep(variant = -1) through k_ref_quad / k_ref_split and through k_sweep_ref / k_sweep_ref2: the oracle's bits,
+    with segments on both sides of both thresholds (4096 and 32768 entries) and four-segment items of mixed lengths."""
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([[40000, 0, 4096, 4095, 4097, 33000, 1, 2, 3, 4, 5, 63, 64, 65, 8191], rng.integers(0, 400, 900), [12000, 0, 0, 7]])
+    ptr = np.zeros(lens.size + 1, np.uint32); ptr[1:] = np.cumsum(lens)
+    nnz, nvec = int(ptr[-1]), 7000
+    idx = rng.integers(0, nvec, nnz).astype(np.uint32)
+    val = rng.uniform(-5, 5, nnz).astype(np.float32)
+    vec = rng.uniform(-1, 1, nvec).astype(np.float32)
+    ref = orc.rank_one_sweep(ptr, idx, val, vec, 0.07, 2)
+    for form in ("1", "0"):
+        monkeypatch.setenv("MFX_REF_FUSED", form)
+        out = mfx.rank_one_sweep(ptr, idx, val, vec, 0.07, -1)
+        assert np.array_equal(bits(out[lens > 0]), bits(ref[lens > 0])), form
+        assert np.all(out[lens == 0] == 0), form
