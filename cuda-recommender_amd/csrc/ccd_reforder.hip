@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kRefBlock) void k_sweep_ref(uint32_t nseg, const ui
 constexpr int kRef2Block = 128;
 constexpr uint32_t kRefLong = 32768;           // k_sweep_ref2 (the as-written sequence, MFX_REF_FUSED=0): entries from which a segment takes the two-wave plain-add form:
                                                // Netflix shape, v-sweep 1.32 ms with 32768 against 1.39-1.49 ms with 8192 ... 1 and 1.93 ms without
-constexpr uint32_t kRefSplit = 4096;           // launch_ref_owner: entries from which a segment goes to k_ref_split (MFX_REF_LONG overrides both, A/B)
+constexpr uint32_t kRefSplit = 2048;           // launch_ref_owner: entries from which a segment goes to k_ref_split (MFX_REF_LONG overrides both, A/B)
 constexpr uint32_t kStage2 = 1024;             // entries per pipeline stage of k_sweep_ref2: 16 per lane (a stage's chain takes ~2 us:
                                                // two stages of loads in flight cover the memory latency; with 256-entry stages they did not)
 using f32x4r = __attribute__((ext_vector_type(4))) float;
@@ -340,10 +340,18 @@ struct RefOwnerArgs {
     float4* pack4;            // out: (prev_new, cur_old, cur_new, 0), may be nullptr
 };
 
+// G: element of the gathered operand; S: the same inside k_ref_quad's LDS table (12 of the 16 bytes of a float4 operand); P: per-segment operand
+struct F3r { float x, y, z; };
 template <int MODE> struct RefTraits;
-template <> struct RefTraits<FM_SWEEP> { using G = float;  using P = float;  static constexpr bool kWrite = false, kPerSeg = false; };
-template <> struct RefTraits<FM_FCSC>  { using G = float2; using P = float2; static constexpr bool kWrite = true,  kPerSeg = true; };
-template <> struct RefTraits<FM_FCSR>  { using G = float4; using P = float2; static constexpr bool kWrite = true,  kPerSeg = true; };
+template <> struct RefTraits<FM_SWEEP> { using G = float;  using S = float;  using P = float;  static constexpr bool kWrite = false, kPerSeg = false; };
+template <> struct RefTraits<FM_FCSC>  { using G = float2; using S = float2; using P = float2; static constexpr bool kWrite = true,  kPerSeg = true; };
+template <> struct RefTraits<FM_FCSR>  { using G = float4; using S = F3r;    using P = float2; static constexpr bool kWrite = true,  kPerSeg = true; };
+__device__ __forceinline__ float to_tab(float g) { return g; }
+__device__ __forceinline__ float2 to_tab(const float2& g) { return g; }
+__device__ __forceinline__ F3r to_tab(const float4& g) { return F3r{g.x, g.y, g.z}; }
+__device__ __forceinline__ float from_tab(float s) { return s; }
+__device__ __forceinline__ float2 from_tab(const float2& s) { return s; }
+__device__ __forceinline__ float4 from_tab(const F3r& s) { return make_float4(s.x, s.y, s.z, 0.f); }
 
 // One element: the new residual value (the reference's unfused update, src/CCD.cpp:25,36 -- element_op of ccd_kernels.hip) and the
 // operand of its two products.
@@ -400,15 +408,22 @@ __device__ __forceinline__ uint32_t rows_max(uint32_t x) {  // wave-uniform maxi
 __device__ __forceinline__ uint32_t quad_pos(const RowSeg& r, uint32_t t, uint32_t lane) { return r.b0 + 64u * t + 4u * (lane & 15u); }
 __device__ __forceinline__ uint32_t quad_at(const RowSeg& r, uint32_t p) { return p < r.hi ? p : 0u; }
 
-template <int MODE>
+// TAB: the operands of the indices below tab_n sit in the workgroup's LDS table (k_ref_quad); only the others go to L2
+template <int MODE, bool TAB = false>
 __device__ __forceinline__ void gather_quad(const RefOwnerArgs& a, const RowSeg& r, uint32_t p, const u32x4r& id,
-                                            typename RefTraits<MODE>::G (&g)[4]) {
+                                            typename RefTraits<MODE>::G (&g)[4], const typename RefTraits<MODE>::S* tab = nullptr, uint32_t tab_n = 0) {
     using G = typename RefTraits<MODE>::G;
     const G* __restrict__ gather = static_cast<const G*>(a.gather);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const uint32_t pos = p + (uint32_t) e;
-        g[e] = gather[(pos >= r.lo && pos < r.hi) ? id[e] : 0u];  // (padding and the neighbours' entries: not this gather's indices)
+        const uint32_t ii = (pos >= r.lo && pos < r.hi) ? id[e] : 0u;  // (padding and the neighbours' entries: not this gather's indices)
+        if constexpr (TAB) {
+            if (ii < tab_n) g[e] = from_tab(tab[ii]);
+            else g[e] = gather[ii];
+        } else {
+            g[e] = gather[ii];
+        }
     }
 }
 // element update + write-back of a quad; the two products of every entry of [lo, hi), +0 elsewhere
@@ -450,14 +465,28 @@ __device__ __forceinline__ void ref_finish(const RefOwnerArgs& a, const RowSeg& 
     }
 }
 
-constexpr int kQuadBlock = 128;
-template <int MODE>
-__global__ __launch_bounds__(kQuadBlock) void k_ref_quad(RefOwnerArgs a) {
+// TAB: the workgroup copies the first tab_n operands of the gather table into LDS once and serves those indices from there.  The
+// plain form's u-pass is bound by its gathers -- every 16-byte operand is a 64-byte sector from L2 (0.72 ms at the Netflix shape, the
+// plain flat pass's 0.57 ms plus the chains) -- and the column operands of that pass are a 17 770-entry table: 13 600 of them fit a CU's
+// LDS as 12-byte triples.  One 1024-thread workgroup per CU then (the table is per workgroup), grid-strided over the items.
+constexpr int kQuadBlock = 128, kQuadTabBlock = 1024;
+constexpr size_t kQuadTabBytes = 160 * 1024 - 512;
+template <int MODE, bool TAB>
+__global__ __launch_bounds__(TAB ? kQuadTabBlock : kQuadBlock) void k_ref_quad(RefOwnerArgs a, uint32_t tab_n) {
     using TR = RefTraits<MODE>;
     using G = typename TR::G;
+    using S = typename TR::S;
     using P = typename TR::P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char quad_lds[];
+    const S* tab = reinterpret_cast<const S*>(quad_lds);
+    if constexpr (TAB) {
+        S* w = reinterpret_cast<S*>(quad_lds);
+        const G* __restrict__ gather = static_cast<const G*>(a.gather);
+        for (uint32_t i = threadIdx.x; i < tab_n; i += blockDim.x) w[i] = to_tab(gather[i]);
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * kQuadBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kQuadBlock) >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t item = a.item0 + wave; item < a.nitems; item += nwaves) {
         const RowSeg r = row_segment(a, item, lane);
         P ps{};
@@ -476,13 +505,13 @@ __global__ __launch_bounds__(kQuadBlock) void k_ref_quad(RefOwnerArgs a) {
             ia = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, pa));
             va = *reinterpret_cast<const f32x4r*>(a.val + quad_at(r, pa));
             ib = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, pb));
-            gather_quad<MODE>(a, r, pa, ia, ga);
+            gather_quad<MODE, TAB>(a, r, pa, ia, ga, tab, tab_n);
             // step: chunk t sits in (v_cur, g_cur), the indices of chunk t + 1 in i_next; i_cur (consumed) takes chunk t + 2's
             auto step = [&](uint32_t t, uint32_t p_cur, uint32_t& p_next, u32x4r& i_cur, const u32x4r& i_next, const f32x4r& v_cur, f32x4r& v_next,
                             const G (&g_cur)[4], G (&g_next)[4]) {
                 p_next = quad_pos(r, t + 1, lane);
                 v_next = *reinterpret_cast<const f32x4r*>(a.val + quad_at(r, p_next));
-                gather_quad<MODE>(a, r, p_next, i_next, g_next);
+                gather_quad<MODE, TAB>(a, r, p_next, i_next, g_next, tab, tab_n);
                 i_cur = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, quad_pos(r, t + 2, lane)));
                 f32x4r xg, xh;
                 quad_terms<MODE, true, true, true>(a, r, p_cur, v_cur, g_cur, ps, xg, xh);
@@ -667,13 +696,45 @@ int launch_ref_owner(FlatMode mode, const SegStreamDev& s, const uint32_t* order
         if (e != hipSuccess) return fail(MFX_ERR_HIP, "k_ref_split launch failed: %s", hipGetErrorString(e));
     }
     if (a.item0 < a.nitems) {
-        const uint32_t waves_per_block = kQuadBlock / 64, nq = a.nitems - a.item0;
-        static const uint32_t cap = [] { const char* e = std::getenv("MFX_REF_QUAD_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t) v : 256u * 16u; }();
-        const uint32_t grid = std::min<uint32_t>((nq + waves_per_block - 1) / waves_per_block, cap);
-        switch (mode) {
-            case FM_SWEEP: hipLaunchKernelGGL(k_ref_quad<FM_SWEEP>, dim3(grid), dim3(kQuadBlock), 0, st_quad, a); break;
-            case FM_FCSC: hipLaunchKernelGGL(k_ref_quad<FM_FCSC>, dim3(grid), dim3(kQuadBlock), 0, st_quad, a); break;
-            default: hipLaunchKernelGGL(k_ref_quad<FM_FCSR>, dim3(grid), dim3(kQuadBlock), 0, st_quad, a); break;
+        const uint32_t nq = a.nitems - a.item0;
+        // the LDS table form when a CU's LDS covers at least a quarter of the operand table (MFX_REF_QUAD_TAB=0: never)
+        static const bool tab_ok = [] { const char* e = std::getenv("MFX_REF_QUAD_TAB"); return !(e && std::atoi(e) == 0); }();
+        const size_t elem = mode == FM_SWEEP ? sizeof(float) : mode == FM_FCSC ? sizeof(float2) : sizeof(F3r);
+        const uint32_t tab_n = (uint32_t) std::min<size_t>(s.gather_len, kQuadTabBytes / elem);
+        const bool tab = tab_ok && tab_n > 0 && (uint64_t) tab_n * 4u >= s.gather_len && nq >= 64u;
+        if (tab) {
+            const size_t lds = (size_t) tab_n * elem;
+            const void* fn = mode == FM_SWEEP ? reinterpret_cast<const void*>(k_ref_quad<FM_SWEEP, true>)
+                             : mode == FM_FCSC ? reinterpret_cast<const void*>(k_ref_quad<FM_FCSC, true>) : reinterpret_cast<const void*>(k_ref_quad<FM_FCSR, true>);
+            if (lds > 48 * 1024) {
+                static std::mutex m;
+                static size_t set_bytes[3][64] = {};
+                int dev = 0;
+                MFX_HIP(hipGetDevice(&dev));
+                const int mi = mode == FM_SWEEP ? 0 : (mode == FM_FCSC ? 1 : 2);
+                std::lock_guard<std::mutex> lk(m);
+                if (dev < 0 || dev >= 64 || set_bytes[mi][dev] < lds) {
+                    MFX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kQuadTabBytes));
+                    if (dev >= 0 && dev < 64) set_bytes[mi][dev] = kQuadTabBytes;
+                }
+            }
+            const uint32_t waves_per_block = kQuadTabBlock / 64;
+            const uint32_t per_cu = (uint32_t) std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / std::max<size_t>(lds, 1)));
+            const uint32_t grid = std::min<uint32_t>((nq + waves_per_block - 1) / waves_per_block, 256u * per_cu);
+            switch (mode) {
+                case FM_SWEEP: hipLaunchKernelGGL((k_ref_quad<FM_SWEEP, true>), dim3(grid), dim3(kQuadTabBlock), lds, st_quad, a, tab_n); break;
+                case FM_FCSC: hipLaunchKernelGGL((k_ref_quad<FM_FCSC, true>), dim3(grid), dim3(kQuadTabBlock), lds, st_quad, a, tab_n); break;
+                default: hipLaunchKernelGGL((k_ref_quad<FM_FCSR, true>), dim3(grid), dim3(kQuadTabBlock), lds, st_quad, a, tab_n); break;
+            }
+        } else {
+            const uint32_t waves_per_block = kQuadBlock / 64;
+            static const uint32_t cap = [] { const char* e = std::getenv("MFX_REF_QUAD_WGS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t) v : 256u * 16u; }();
+            const uint32_t grid = std::min<uint32_t>((nq + waves_per_block - 1) / waves_per_block, cap);
+            switch (mode) {
+                case FM_SWEEP: hipLaunchKernelGGL((k_ref_quad<FM_SWEEP, false>), dim3(grid), dim3(kQuadBlock), 0, st_quad, a, 0u); break;
+                case FM_FCSC: hipLaunchKernelGGL((k_ref_quad<FM_FCSC, false>), dim3(grid), dim3(kQuadBlock), 0, st_quad, a, 0u); break;
+                default: hipLaunchKernelGGL((k_ref_quad<FM_FCSR, false>), dim3(grid), dim3(kQuadBlock), 0, st_quad, a, 0u); break;
+            }
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(MFX_ERR_HIP, "k_ref_quad launch failed: %s", hipGetErrorString(e));
@@ -692,10 +753,14 @@ uint32_t ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<ui
     std::stable_sort(order->begin(), order->end(), [&](uint32_t x, uint32_t y) {
         return ptr_host[x + 1] - ptr_host[x] > ptr_host[y + 1] - ptr_host[y];
     });
-    static const uint32_t env_thr = [] { const char* e = std::getenv("MFX_REF_LONG"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t) v : 0u; }();
+    const uint32_t env_thr = [] { const char* e = std::getenv("MFX_REF_LONG"); const int v = e ? std::atoi(e) : 0; return v > 0 ? (uint32_t) v : 0u; }();  // (A/B, tests)
     const uint32_t thr = env_thr ? env_thr : (owner_form ? kRefSplit : kRefLong);
     uint32_t nlong = 0;
     while (nlong < nseg && nlong < 8192u && ptr_host[(*order)[nlong] + 1] - ptr_host[(*order)[nlong]] >= thr) ++nlong;
+    // owner form: the split kernel (and the second stream it costs) only where some segment is long for a k_ref_quad wave -- a wave
+    // advances ~64 entries per memory round trip, 8192 entries in ~0.1 ms (Netflix shape, rows of up to 17 770 entries: 70.4 ms per
+    // outer iteration with the row side's 1240 rows of >= 2048 entries on the split kernel, 72.0 ms without)
+    if (owner_form && !env_thr && nseg && ptr_host[(*order)[0] + 1] - ptr_host[(*order)[0]] < 8192u) nlong = 0;
     return nlong;
 }
 

@@ -757,6 +757,8 @@ int CcdSolver::init(const mfx_csx* R, const mfx_coo* T, const mfx_params* p, mfx
             MFX_HIP(hipStreamSynchronize(st_));
         }
         if (ref_fused_) {
+            // (the owner passes have no sweep / update split to report: launch events only when profiling is asked for)
+            prof_.enable(p->profile != 0);
             ref_streams_.main = st_;
             MFX_HIP(hipStreamCreateWithFlags(&ref_streams_.side, hipStreamNonBlocking));
             MFX_HIP(hipEventCreateWithFlags(&ref_streams_.fork, hipEventDisableTiming));
@@ -1435,7 +1437,7 @@ int CcdSolver::iterate(int n_outer, int with_rmse, mfx_iter_report* reports) {
 int CcdSolver::set_profile(bool on) {
     // (schedule 0 keeps its launch events on regardless: its rank/update split is derived from them)
     p_.profile = on ? 1 : 0;
-    prof_.enable(on || p_.schedule == 0);
+    prof_.enable(on || (p_.schedule == 0 && !ref_fused_));
     prof_.reset_totals();
     return MFX_OK;
 }

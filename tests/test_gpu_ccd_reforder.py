@@ -200,9 +200,12 @@ def test_reference_order_owner_passes_equal_the_as_written_sequence(mfx, orc, mo
     W0 = mfx.initial_col(k, d.rows)
     Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, T, orc.max_threads())
     out = {}
-    for form in ("1", "0"):
-        monkeypatch.setenv("MFX_REF_FUSED", form)
+    for form in ("1", "0", "split"):
+        monkeypatch.setenv("MFX_REF_FUSED", "0" if form == "0" else "1")
+        if form == "split":  # (by default a side takes the split kernel only when one of its segments has >= 32768 entries)
+            monkeypatch.setenv("MFX_REF_LONG", "4096")
         out[form] = _solve(mfx, d, W0, k, lam, t, T)
+    monkeypatch.delenv("MFX_REF_LONG")
     for form, (W, H, csc, csr, rmse) in out.items():
         assert np.array_equal(bits(W), bits(Wr)) and np.array_equal(bits(H), bits(Hr)), form
         assert np.array_equal(bits(csc), bits(csc_ref)) and np.array_equal(bits(csr), bits(csr_ref)), form
@@ -220,7 +223,7 @@ def test_reference_order_sweep_op_both_forms(mfx, orc, monkeypatch):
     val = rng.uniform(-5, 5, nnz).astype(np.float32)
     vec = rng.uniform(-1, 1, nvec).astype(np.float32)
     ref = orc.rank_one_sweep(ptr, idx, val, vec, 0.07, 2)
-    for form in ("1", "0"):
+    for form in ("1", "0"):  # (the 40 000-entry segment puts this side's long segments on the split kernel)
         monkeypatch.setenv("MFX_REF_FUSED", form)
         out = mfx.rank_one_sweep(ptr, idx, val, vec, 0.07, -1)
         assert np.array_equal(bits(out[lens > 0]), bits(ref[lens > 0])), form
