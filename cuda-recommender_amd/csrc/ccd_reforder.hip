@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kRef2Block) void k_sweep_ref2(uint32_t nseg, uint32
 //   k_ref_quad   one wavefront per item (4 segments, longest first), both chains (g, h) interleaved: issue-bound; loads two chunks
 //                ahead, the gather one chunk ahead, many waves per SIMD.  A throughput form: a wave's own progress on a long segment is
 //                one memory round trip per chunk (a 150 000-entry column takes it 2 ms).
-//   k_ref_split  items whose longest segment has >= kRefSplit = 4096 entries: a 512-thread workgroup per item.  Wave 0 runs the four g
+//   k_ref_split  items whose longest segment has >= kRefSplit = 2048 entries: a 512-thread workgroup per item.  Wave 0 runs the four g
 //                chains and wave 1 the four h chains -- ONE dependent add per entry and nothing else: their terms come from LDS, 64
 //                per ds_read_b128, put there a batch of 36 chunks ahead by the six loader waves (loads, gather, element update,
 //                write-back of r', products), one LDS-only barrier per batch.  What it took to make the chains the bound
@@ -313,10 +313,11 @@ __global__ __launch_bounds__(kRef2Block) void k_sweep_ref2(uint32_t nseg, uint32
 //                    register file (the `asm volatile("" ::: "v255")`), and it is launched FIRST, on the main stream, with k_ref_quad
 //                    behind it on the side stream, so that its workgroups are placed before the first quad wave.
 //                  * with that, the split form is also the efficient one for every segment that keeps a CU busy (a CU serves four
-//                    chains at full speed): the threshold went from 32768 to 4096 entries (sweep: 147 ms per outer iteration at
-//                    16384, 115 at 8192, 95 at 4096, 99 at 2048, 95.5 at 1024; 120 / 143 / 177 ms at 65536 / 100 000 / 150 000).
-// Netflix shape, k = 64: v-pass 0.72 ms (the 237 k-entry chain), u-pass 0.72 ms (k_ref_quad, bound by the L2 gather like the plain flat
-// pass), the mode 201 -> 95 ms per outer iteration (profiles/r04_bench_reforder.json).
+//                    chains at full speed): the threshold went from 32768 to 2048 entries (per outer iteration, with the LDS table
+//                    below: 102 ms at 8192, 92 at 6144, 80 at 4096, 71.5 at 3072, 70.4 at 2048, 69-70 at 1536 ... 512; before the
+//                    table 147 ms at 16384, 120 / 143 / 177 ms at 65536 / 100 000 / 150 000).
+// Netflix shape, k = 64: v-pass 0.59 ms (the 237 k-entry chain), u-pass 0.47 ms (k_ref_quad with the LDS table; 0.72 ms without, bound by
+// the L2 gather like the plain flat pass), the mode 201 -> 70 ms per outer iteration (profiles/r04_bench_reforder.json).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sub_rn(float a, float b) {
 #pragma clang fp contract(off)
@@ -697,11 +698,14 @@ int launch_ref_owner(FlatMode mode, const SegStreamDev& s, const uint32_t* order
     }
     if (a.item0 < a.nitems) {
         const uint32_t nq = a.nitems - a.item0;
-        // the LDS table form when a CU's LDS covers at least a quarter of the operand table (MFX_REF_QUAD_TAB=0: never)
-        static const bool tab_ok = [] { const char* e = std::getenv("MFX_REF_QUAD_TAB"); return !(e && std::atoi(e) == 0); }();
+        // the LDS table form when a CU's LDS covers at least a quarter of the operand table (MFX_REF_QUAD_TAB=0: never; = n > 1: a table
+        // of n bytes whatever it covers -- tests and the fuzzer exercise partly covered tables on small matrices with it)
+        const char* tab_env = std::getenv("MFX_REF_QUAD_TAB");
+        const long tab_set = tab_env ? std::atol(tab_env) : -1;
         const size_t elem = mode == FM_SWEEP ? sizeof(float) : mode == FM_FCSC ? sizeof(float2) : sizeof(F3r);
-        const uint32_t tab_n = (uint32_t) std::min<size_t>(s.gather_len, kQuadTabBytes / elem);
-        const bool tab = tab_ok && tab_n > 0 && (uint64_t) tab_n * 4u >= s.gather_len && nq >= 64u;
+        const size_t tab_bytes = tab_set > 1 ? std::min<size_t>((size_t) tab_set, kQuadTabBytes) : kQuadTabBytes;
+        const uint32_t tab_n = (uint32_t) std::min<size_t>(s.gather_len, tab_bytes / elem);
+        const bool tab = tab_set != 0 && tab_n > 0 && (tab_set > 1 || ((uint64_t) tab_n * 4u >= s.gather_len && nq >= 64u));
         if (tab) {
             const size_t lds = (size_t) tab_n * elem;
             const void* fn = mode == FM_SWEEP ? reinterpret_cast<const void*>(k_ref_quad<FM_SWEEP, true>)

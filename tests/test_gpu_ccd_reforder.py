@@ -200,12 +200,16 @@ def test_reference_order_owner_passes_equal_the_as_written_sequence(mfx, orc, mo
     W0 = mfx.initial_col(k, d.rows)
     Wr, Hr, rmse_ref, _, csc_ref, csr_ref = orc.ccdr1(d, W0, k, lam, t, T, orc.max_threads())
     out = {}
-    for form in ("1", "0", "split"):
+    for form in ("1", "0", "split", "table"):
         monkeypatch.setenv("MFX_REF_FUSED", "0" if form == "0" else "1")
-        if form == "split":  # (by default a side takes the split kernel only when one of its segments has >= 32768 entries)
+        if form == "split":  # (by default a side takes the split kernel only when one of its segments has >= 8192 entries)
             monkeypatch.setenv("MFX_REF_LONG", "4096")
+        if form == "table":  # k_ref_quad's LDS table holding a part of the operands only (as at the Netflix shape), and no split kernel
+            monkeypatch.setenv("MFX_REF_LONG", "100000000")
+            monkeypatch.setenv("MFX_REF_QUAD_TAB", "30000")
         out[form] = _solve(mfx, d, W0, k, lam, t, T)
-    monkeypatch.delenv("MFX_REF_LONG")
+        monkeypatch.delenv("MFX_REF_LONG", raising=False)
+        monkeypatch.delenv("MFX_REF_QUAD_TAB", raising=False)
     for form, (W, H, csc, csr, rmse) in out.items():
         assert np.array_equal(bits(W), bits(Wr)) and np.array_equal(bits(H), bits(Hr)), form
         assert np.array_equal(bits(csc), bits(csc_ref)) and np.array_equal(bits(csr), bits(csr_ref)), form

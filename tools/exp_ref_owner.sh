@@ -15,7 +15,7 @@ one() {  # label, env...
   python3 $REPO/tools/prof_db.py $REPO/gpurun_out/r4b/prof_e k_ | cut -c28-52,105-200 >> $OUT
   grep -o '"ms_per_step": [0-9.]*' $REPO/gpurun_out/r4b/prof_e.log | head -1 >> $OUT
 }
-one "default (owner passes, threshold 4096)" MFX_REF_FUSED=1
+one "default (owner passes, split from 2048 entries where a side has a segment of >= 8192)" MFX_REF_FUSED=1
 for L in 1024 2048 8192 32768 150000; do one "threshold $L" MFX_REF_LONG=$L; done
 for W in 512 2048; do one "k_ref_quad capped at $W workgroups" MFX_REF_QUAD_WGS=$W; done
 one "as-written sequence (MFX_REF_FUSED=0)" MFX_REF_FUSED=0

@@ -67,6 +67,15 @@ for case in range(a.cases):
         os.environ["MFX_COMM_RESERVE_CUS"] = str(int(rng.choice([0, 16, 200])))
     elif lay == "reforder":  # the reference's summation order: bit-identical to the oracle (r3)
         p.schedule, p.kernel_variant = 0, -1
+        # (r4) the owner passes (k_ref_quad / k_ref_split, with random split thresholds and with / without the LDS table) or the
+        # as-written sequence
+        os.environ["MFX_REF_FUSED"] = str(int(rng.choice([1, 1, 1, 0])))
+        thr = int(rng.choice([0, 0, 1, 8, 64, 300, 2048]))
+        if thr: os.environ["MFX_REF_LONG"] = str(thr)
+        else: os.environ.pop("MFX_REF_LONG", None)
+        tabb = int(rng.choice([-1, -1, 0, 64, 1000, 20000]))  # LDS table of k_ref_quad: default rule, never, or this many bytes (partly covered tables)
+        if tabb >= 0: os.environ["MFX_REF_QUAD_TAB"] = str(tabb)
+        else: os.environ.pop("MFX_REF_QUAD_TAB", None)
     p.tiles_per_span = int(rng.choice([0, 2, 4, 16]))
     p.wg_waves = int(rng.choice([0, 4, 8, 16]))
     p.graph = int(rng.choice([0, -1]))
