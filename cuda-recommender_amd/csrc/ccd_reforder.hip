@@ -420,8 +420,11 @@ __device__ __forceinline__ void gather_quad(const RefOwnerArgs& a, const RowSeg&
         const uint32_t pos = p + (uint32_t) e;
         const uint32_t ii = (pos >= r.lo && pos < r.hi) ? id[e] : 0u;  // (padding and the neighbours' entries: not this gather's indices)
         if constexpr (TAB) {
-            if (ii < tab_n) g[e] = from_tab(tab[ii]);
-            else g[e] = gather[ii];
+            // both loads, unconditionally (the global one of a table-served lane re-reads operand 0: one request for all of them): a load
+            // inside a branch makes every s_waitcnt the compiler derives afterwards allow for it NOT having been issued -- too strict
+            const G from_l2 = gather[ii < tab_n ? 0u : ii];
+            const G from_lds = from_tab(tab[ii < tab_n ? ii : 0u]);
+            g[e] = ii < tab_n ? from_lds : from_l2;
         } else {
             g[e] = gather[ii];
         }
@@ -497,31 +500,35 @@ __global__ __launch_bounds__(TAB ? kQuadTabBlock : kQuadBlock) void k_ref_quad(R
         float sg = 0.f, sh = mul_rn(a.lambda, (float) (r.hi - r.lo));  // float * unsigned (src/CCD.cpp:112,120)
         const uint32_t nmax = rows_max(r.nch);
         if (nmax) {
-            // in flight: the indices of chunk t + 2, the values and the gather of chunk t + 1, the chains of chunk t.  Two register
-            // sets that swap roles every chunk (the loop is unrolled by two: no copies).
-            u32x4r ia, ib;
-            f32x4r va, vb;
+            // A ring of four chunks: the indices and values of chunks t + 1 ... t + 3 are in flight (or here) while chunk t runs its
+            // chains; the gather of chunk t + 1 goes out one chunk ahead (two operand sets, alternating).  Rows of up to 256 entries
+            // -- the typical user row -- have ALL their loads issued at once (a first version kept two chunks in flight and paid
+            // one memory round trip per chunk).  The loop is unrolled by the ring size: every register index is static.
+            u32x4r I[4];
+            f32x4r V[4];
             G ga[4], gb[4];
-            uint32_t pa = quad_pos(r, 0, lane), pb = quad_pos(r, 1, lane);
-            ia = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, pa));
-            va = *reinterpret_cast<const f32x4r*>(a.val + quad_at(r, pa));
-            ib = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, pb));
-            gather_quad<MODE, TAB>(a, r, pa, ia, ga, tab, tab_n);
-            // step: chunk t sits in (v_cur, g_cur), the indices of chunk t + 1 in i_next; i_cur (consumed) takes chunk t + 2's
-            auto step = [&](uint32_t t, uint32_t p_cur, uint32_t& p_next, u32x4r& i_cur, const u32x4r& i_next, const f32x4r& v_cur, f32x4r& v_next,
-                            const G (&g_cur)[4], G (&g_next)[4]) {
-                p_next = quad_pos(r, t + 1, lane);
-                v_next = *reinterpret_cast<const f32x4r*>(a.val + quad_at(r, p_next));
-                gather_quad<MODE, TAB>(a, r, p_next, i_next, g_next, tab, tab_n);
-                i_cur = *reinterpret_cast<const u32x4r*>(a.idx + quad_at(r, quad_pos(r, t + 2, lane)));
-                f32x4r xg, xh;
-                quad_terms<MODE, true, true, true>(a, r, p_cur, v_cur, g_cur, ps, xg, xh);
-                chain_two(sg, sh, xg, xh);
-            };
-            for (uint32_t t = 0; t < nmax; t += 2) {
-                step(t, pa, pb, ia, ib, va, vb, ga, gb);
-                if (t + 1 >= nmax) break;
-                step(t + 1, pb, pa, ib, ia, vb, va, gb, ga);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t at = quad_at(r, quad_pos(r, (uint32_t) d, lane));
+                I[d] = *reinterpret_cast<const u32x4r*>(a.idx + at);
+                V[d] = *reinterpret_cast<const f32x4r*>(a.val + at);
+            }
+            gather_quad<MODE, TAB>(a, r, quad_pos(r, 0, lane), I[0], ga, tab, tab_n);
+            for (uint32_t t0 = 0; t0 < nmax; t0 += 4) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t t = t0 + (uint32_t) d;
+                    if (t >= nmax) break;
+                    G (&g_cur)[4] = (d & 1) ? gb : ga;
+                    G (&g_next)[4] = (d & 1) ? ga : gb;
+                    gather_quad<MODE, TAB>(a, r, quad_pos(r, t + 1, lane), I[(d + 1) & 3], g_next, tab, tab_n);
+                    f32x4r xg, xh;
+                    quad_terms<MODE, true, true, true>(a, r, quad_pos(r, t, lane), V[d], g_cur, ps, xg, xh);
+                    const uint32_t at = quad_at(r, quad_pos(r, t + 4, lane));  // (this set's indices went into the gather a chunk ago)
+                    I[d] = *reinterpret_cast<const u32x4r*>(a.idx + at);
+                    V[d] = *reinterpret_cast<const f32x4r*>(a.val + at);
+                    chain_two(sg, sh, xg, xh);
+                }
             }
         }
         if (r.have && (lane & 15u) == 0) ref_finish<MODE>(a, r, sg, sh, ps, next_old);
@@ -761,10 +768,10 @@ uint32_t ref_sweep_order(const uint32_t* ptr_host, uint32_t nseg, std::vector<ui
     const uint32_t thr = env_thr ? env_thr : (owner_form ? kRefSplit : kRefLong);
     uint32_t nlong = 0;
     while (nlong < nseg && nlong < 8192u && ptr_host[(*order)[nlong] + 1] - ptr_host[(*order)[nlong]] >= thr) ++nlong;
-    // owner form: the split kernel (and the second stream it costs) only where some segment is long for a k_ref_quad wave -- a wave
-    // advances ~64 entries per memory round trip, 8192 entries in ~0.1 ms (Netflix shape, rows of up to 17 770 entries: 70.4 ms per
-    // outer iteration with the row side's 1240 rows of >= 2048 entries on the split kernel, 72.0 ms without)
-    if (owner_form && !env_thr && nseg && ptr_host[(*order)[0] + 1] - ptr_host[(*order)[0]] < 8192u) nlong = 0;
+    // owner form: the split kernel (and the second stream it costs) only where it has work -- a segment of >= 8192 entries (long for a
+    // k_ref_quad wave, which advances a chunk per memory round trip) or at least 64 segments over the threshold (Netflix shape: 67-70 ms
+    // per outer iteration with the row side's 1240 rows of >= 2048 entries on the split kernel, 71-72 ms without)
+    if (owner_form && !env_thr && nseg && ptr_host[(*order)[0] + 1] - ptr_host[(*order)[0]] < 8192u && nlong < 64u) nlong = 0;
     return nlong;
 }
 

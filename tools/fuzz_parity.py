@@ -17,6 +17,7 @@ ap.add_argument("--cases", type=int, default=200)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--seconds", type=float, default=240.0)
 ap.add_argument("--only", type=int, default=-1, help="run just this case index (same random stream), with diagnostics")
+ap.add_argument("--layouts", default="", help="comma-separated subset of the layout / schedule kinds to draw from (e.g. reforder)")
 ap.add_argument("--big", action="store_true", help="mid-size shapes (4-20 M ratings) where the automatic layout choice picks LDS / cache panels")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -52,6 +53,8 @@ for case in range(a.cases):
     t = int(rng.choice([1, 2, 3]))
     p = mfx.parameter(); p.k, p.lambda_, p.maxiter, p.maxinneriter = k, lam, t, T
     lay = rng.choice(["auto", "auto", "lds", "cache"] if a.big else ["auto", "plain", "lds", "cache", "hostbuilt", "wave", "written_flat", "scatter", "scatter", "reforder", "reforder"])
+    if a.layouts:
+        lay = rng.choice(a.layouts.split(","))
     if lay == "plain": p.panel_rows = -1
     elif lay == "lds": p.panel_rows = int(rng.choice([16, 100, 1000, 7000]))
     elif lay == "cache": p.panel_rows = -int(rng.choice([16, 100, 5000]))
