@@ -491,12 +491,46 @@ __global__ __launch_bounds__(TAB ? kQuadTabBlock : kQuadBlock) void k_ref_quad(R
     }
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t item = a.item0 + wave; item < a.nitems; item += nwaves) {
-        const RowSeg r = row_segment(a, item, lane);
-        P ps{};
-        if constexpr (TR::kPerSeg) { if (r.have) ps = static_cast<const P*>(a.perseg)[r.c]; }
-        float next_old = 0.f;
-        if constexpr (MODE != FM_SWEEP) { if (r.have && a.next_vec) next_old = a.next_vec[r.c]; }
+    // An item's start-up is a chain of dependent loads: order -> pointers (+ per-segment operands) -> indices -> gather.  The first two
+    // links are taken off it: while item i runs, the pointers and operands of item i + 1 (whose segment ids arrived during item i - 1)
+    // and the segment ids of item i + 2 are in flight.  All of these loads are unconditional (an absent segment re-reads segment 0 and
+    // is voided afterwards): see gather_quad on conditional loads and the compiler's wait counts.
+    struct Meta { uint32_t c, lo, hi; P ps; float next_old; };
+    auto seg_id = [&](uint32_t it, bool& have) {  // (it may lie past the last item: wave-uniformly voided)
+        const uint32_t q = 4u * it + (lane >> 4);
+        have = it < a.nitems && q < a.nseg;
+        return a.order[have ? q : 0u];
+    };
+    auto fetch_meta = [&](uint32_t c, bool have) {
+        Meta m;
+        m.c = have ? c : 0u;
+        m.lo = a.ptr[m.c];
+        m.hi = a.ptr[m.c + 1];
+        m.ps = P{};
+        if constexpr (TR::kPerSeg) m.ps = static_cast<const P*>(a.perseg)[m.c];
+        m.next_old = 0.f;
+        if constexpr (MODE != FM_SWEEP) m.next_old = a.next_vec[m.c];
+        if (!have) m.lo = m.hi = 0u;
+        return m;
+    };
+    auto row_of = [&](const Meta& m, bool have) {
+        RowSeg r;
+        r.have = have; r.c = m.c; r.lo = m.lo; r.hi = m.hi;
+        r.b0 = r.lo & ~3u;
+        r.nch = r.hi > r.lo ? (r.hi - r.b0 + 63u) / 64u : 0u;
+        return r;
+    };
+    uint32_t item = a.item0 + wave;
+    bool have_cur, have_nxt, have_n2;
+    const uint32_t c0 = seg_id(item, have_cur);
+    uint32_t c_nxt = seg_id(item + nwaves, have_nxt);
+    Meta m_cur = fetch_meta(c0, have_cur);
+    for (; item < a.nitems; item += nwaves) {
+        const Meta m_nxt = fetch_meta(c_nxt, have_nxt);             // item + nwaves: used after this item
+        const uint32_t c_n2 = seg_id(item + 2u * nwaves, have_n2);  // item + 2 nwaves: its pointers are fetched during the next item
+        const RowSeg r = row_of(m_cur, have_cur);
+        const P ps = m_cur.ps;
+        const float next_old = m_cur.next_old;
         float sg = 0.f, sh = mul_rn(a.lambda, (float) (r.hi - r.lo));  // float * unsigned (src/CCD.cpp:112,120)
         const uint32_t nmax = rows_max(r.nch);
         if (nmax) {
@@ -532,6 +566,8 @@ __global__ __launch_bounds__(TAB ? kQuadTabBlock : kQuadBlock) void k_ref_quad(R
             }
         }
         if (r.have && (lane & 15u) == 0) ref_finish<MODE>(a, r, sg, sh, ps, next_old);
+        m_cur = m_nxt; have_cur = have_nxt;
+        c_nxt = c_n2; have_nxt = have_n2;
     }
 }
 

@@ -115,7 +115,7 @@ for wl in sorted(os.listdir(src)) if os.path.isdir(src) else []:
         with open(os.path.join(dst, f"{tag}_pmc_{wl}.txt"), "w") as out:
             for p in pmc_dirs:
                 out.write(f"== rocprofv3 --pmc pass: {os.path.basename(p)[4:]}\n")
-                out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parse_pmc.py"), p, "re:k_flat|k_scatter|k_finalize|k_combine|k_als|k_sweep|k_resid"], capture_output=True, text=True).stdout)
+                out.write(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parse_pmc.py"), p, "re:k_flat|k_scatter|k_finalize|k_combine|k_als|k_sweep|k_resid|k_ref_"], capture_output=True, text=True).stdout)
     if not lines:
         continue
     bench = json.loads(lines[-1])

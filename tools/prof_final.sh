@@ -33,6 +33,9 @@ want ml100k    && run_set ml100k    "--rows 943 --cols 1682 --nnz 100000 --k 10 
 # the panel-group overlap of the sharded column pass on ONE GPU (1-rank RCCL communicator): bench line, kernel stats, and where the
 # exchange kernels ran relative to the column passes (tools/overlap_from_trace.py on the same kernel trace)
 want shardov   && { export MFX_OVERLAP_GROUPS=2 MFX_COMM_RESERVE_CUS=16; run_set shardov "$SHARD --k 128 --steps 2 --warmup 1 --force-comm --no-cpu-baseline --no-rank-one" "$SHARD --k 8 --steps 2 --warmup 1 --force-comm"; unset MFX_OVERLAP_GROUPS MFX_COMM_RESERVE_CUS; python3 tools/overlap_from_trace.py $F/shardov/stats > $F/shardov/extra_overlap.txt 2>&1 < /dev/null; cat $F/shardov/extra_overlap.txt; }
+# the reference-order parity mode (kernel_variant -1): owner passes in the reference's summation order (ccd_reforder.hip)
+REF="--schedule 0 --variant -1 --no-als --no-rank-one"
+want reforder  && run_set reforder  "$REF --steps 3 --warmup 1 --no-cpu-baseline" "$REF --steps 1 --warmup 1" "FETCH_SIZE" "WRITE_SIZE" "$SQ"
 want als       && run_set als       "--solver als --steps 3 --warmup 1" "--solver als --steps 2 --warmup 1" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"
 want als128    && run_set als128    "--solver als --k 128 --steps 3 --warmup 1" "--solver als --k 128 --steps 2 --warmup 1"
 echo "prof_final done"
