@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kRef2Block) void k_sweep_ref2(uint32_t nseg, uint32
 //                    below: 102 ms at 8192, 92 at 6144, 80 at 4096, 71.5 at 3072, 70.4 at 2048, 69-70 at 1536 ... 512; before the
 //                    table 147 ms at 16384, 120 / 143 / 177 ms at 65536 / 100 000 / 150 000).
 // Netflix shape, k = 64: v-pass 0.59 ms (the 237 k-entry chain), u-pass 0.47 ms (k_ref_quad with the LDS table; 0.72 ms without, bound by
-// the L2 gather like the plain flat pass), the mode 201 -> 70 ms per outer iteration (profiles/r04_bench_reforder.json).
+// the L2 gather like the plain flat pass), the mode 201 -> 66-68 ms per outer iteration (profiles/r04_bench_reforder.json).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sub_rn(float a, float b) {
 #pragma clang fp contract(off)
