@@ -25,6 +25,11 @@ def load(spec):
     if spec.startswith("synth:"):
         r, c, z = (int(x) for x in spec[6:].split("x"))
         return mfx.dataset.synth_ratings(r, c, z, seed=1234, skew=0.9)
+    if spec.startswith("synthdev:"):  # generated on the GPU (numpy's rejection sampling takes minutes beyond a few million ratings)
+        import torch  # noqa: F401
+        from mfx import synth_torch
+        r, c, z = (int(x) for x in spec[9:].split("x"))
+        return synth_torch.to_rating_data(synth_torch.synth_ratings_device(r, c, z, seed=1234, device="cuda:0"))
     return mfx.dataset.read_dataset_dir(spec)
 
 
@@ -38,10 +43,14 @@ def main():
     ap.add_argument("--als", action="store_true", help="the ALS half of the protocol (scripts/times.sh:41-66)")
     ap.add_argument("--ks", type=int, nargs="*", default=KS)
     ap.add_argument("--ts", type=int, nargs="*", default=TS)
+    ap.add_argument("--summary", default="", help="also write a table: median GPU seconds per (dataset, K, T) over the repeats")
     a = ap.parse_args()
+    table = {}
     out = sys.stdout if a.out == "-" else open(a.out, "a")
+    d_nnz = {}
     for spec in a.datasets:
         d = load(spec)
+        d_nnz[spec] = d.nnz
         T = mfx.test_data_of(d)
         for k in a.ks:
             for t_inner in ([1] if a.als else a.ts):
@@ -64,6 +73,14 @@ def main():
                                           "gpu_s": round(gpu, 5), "nnz_per_s_per_iter": round(d.nnz * a.iters / gpu, 1) if gpu else None,
                                           "rmse": [round(r.rmse, 6) for r in reports]}) + "\n")
                     out.flush()
+                    table.setdefault((spec, k, t_inner), []).append((gpu, wall, reports[-1].rmse if reports else float("nan")))
+    if a.summary:
+        with open(a.summary, "a") as f:
+            f.write("# dataset  K  T  iters  median GPU s (solver's rank + update time)  median wall s (upload + setup + solve)  nnz/s per outer iteration  final test RMSE\n")
+            for (spec, k, t_inner), v in table.items():
+                g = sorted(x[0] for x in v)[len(v) // 2]
+                w = sorted(x[1] for x in v)[len(v) // 2]
+                f.write(f"{spec} {k} {t_inner} {a.iters} {g:.4f} {w:.3f} {d_nnz[spec] * a.iters / g:.3e} {v[-1][2]:.5f}\n")
 
 
 if __name__ == "__main__":
