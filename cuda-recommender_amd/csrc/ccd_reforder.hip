@@ -746,7 +746,10 @@ int launch_ref_owner(FlatMode mode, const SegStreamDev& s, const uint32_t* order
         const char* tab_env = std::getenv("MFX_REF_QUAD_TAB");
         const long tab_set = tab_env ? std::atol(tab_env) : -1;
         const size_t elem = mode == FM_SWEEP ? sizeof(float) : mode == FM_FCSC ? sizeof(float2) : sizeof(F3r);
-        const size_t tab_bytes = tab_set > 1 ? std::min<size_t>((size_t) tab_set, kQuadTabBytes) : kQuadTabBytes;
+        const char* cap_env = std::getenv("MFX_REF_QUAD_TAB_BYTES");  // (A/B: a smaller table under the default rule -- two workgroups per CU from 80 KB down:
+                                                                      // Netflix shape 73.4 ms per outer iteration with 80 KB, 71.7 with 106 KB, 75.2 with 53 KB, 66-68 with the full 160 KB)
+        const size_t tab_cap = cap_env && std::atol(cap_env) > 0 ? std::min<size_t>((size_t) std::atol(cap_env), kQuadTabBytes) : kQuadTabBytes;
+        const size_t tab_bytes = tab_set > 1 ? std::min<size_t>((size_t) tab_set, kQuadTabBytes) : tab_cap;
         const uint32_t tab_n = (uint32_t) std::min<size_t>(s.gather_len, tab_bytes / elem);
         const bool tab = tab_set != 0 && tab_n > 0 && (tab_set > 1 || ((uint64_t) tab_n * 4u >= s.gather_len && nq >= 64u));
         if (tab) {
