@@ -19,8 +19,10 @@
 // and after l + 1 steps lane l holds ((carry + x_0) + x_1) + ... + x_l, the reference's own chain.  The chain
 // is inherently serial (fp32 addition is not associative): one dependent add per entry and sum, ~12 clocks
 // per entry for g and h together, i.e. ~1.2 ms for a 237 k-entry column.  Segments are dispatched longest
-// first so that such a column starts at once and the short ones fill in behind it.  A parity mode, not a
-// fast path: no LDS panels, the gather goes to L2.
+// first so that such a column starts at once and the short ones fill in behind it.
+// This first form (k_sweep_ref, and k_sweep_ref2 below it) is the as-written sequence of the mode, one launch per
+// reference kernel (MFX_REF_FUSED=0); the default since the second half of round 4 are the owner passes at the end
+// of this file: quad-row chains at 5.75 clocks per entry on the default path's schedule.
 #include "ccd_kernels.hpp"
 
 #include <algorithm>
