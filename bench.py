@@ -333,7 +333,7 @@ def main() -> None:
     ap.add_argument("--strong-steps", type=int, default=2, help="timed outer iterations of the config5_strong leg, per overlap setting")
     ap.add_argument("--no-rank-one", action="store_true",
                     help="skip the standalone rank-one sweep measurement (one extra outer iteration at T = 2, N = 1 only)")
-    ap.add_argument("--cpu-ranks", type=int, default=4, help="ranks the CPU baseline times (scaled to k)")
+    ap.add_argument("--cpu-ranks", type=int, default=16, help="ranks the CPU baseline times (scaled to k): 16 of 64 = ~1 s per outer iteration on 16 cores, two iterations")
     ap.add_argument("--workload", choices=["netflix", "config5", "nnz1e9"], default="netflix",
                     help="netflix: BASELINE configs[2], one 480189-row block per GPU (weak scaling, the metric's "
                          "config); config5: BASELINE configs[4], one global 10M x 1M x 1e9 matrix at k = 128 "
