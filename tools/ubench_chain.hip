@@ -57,6 +57,20 @@ __global__ __launch_bounds__(64) void k_chain(int iters, const float* __restrict
               "v_add_f32_dpp %0, %4, %0 row_newbcast:" #J " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
             asm volatile("s_nop 1\n" A4(0) A4(1) A4(2) A4(3) A4(4) A4(5) A4(6) A4(7) A4(8) A4(9) A4(10) A4(11) A4(12) A4(13) A4(14) A4(15)
                          : "+v"(s) : "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+        } else if constexpr (KIND == 8) {
+            // sixteen chains per wave: every QUAD of lanes carries one sum, lane k of the quad holds entries 16 m + 4 k ... + 3 of the quad's
+            // 64-entry chunk in x_m (m = 0 ... 3); the add takes lane k of the quad through quad_perm:[k,k,k,k]
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(&terms[((i * 64) & 960) + 4 * (threadIdx.x & 3)]);
+            const f32x4 xb = *reinterpret_cast<const f32x4*>(&terms[((i * 64) & 960) + 16 + 4 * (threadIdx.x & 3)]);
+            const f32x4 xc = *reinterpret_cast<const f32x4*>(&terms[((i * 64) & 960) + 32 + 4 * (threadIdx.x & 3)]);
+            const f32x4 xd = *reinterpret_cast<const f32x4*>(&terms[((i * 64) & 960) + 48 + 4 * (threadIdx.x & 3)]);
+#define Q1(X, K) "v_add_f32_dpp %0, " X ", %0 quad_perm:[" #K "," #K "," #K "," #K "] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define Q4(A, B, C, D, K) Q1(A, K) Q1(B, K) Q1(C, K) Q1(D, K)
+#define Q16(A, B, C, D) Q4(A, B, C, D, 0) Q4(A, B, C, D, 1) Q4(A, B, C, D, 2) Q4(A, B, C, D, 3)
+            asm volatile("s_nop 1\n" Q16("%1", "%2", "%3", "%4") Q16("%5", "%6", "%7", "%8") Q16("%9", "%10", "%11", "%12") Q16("%13", "%14", "%15", "%16")
+                         : "+v"(s)
+                         : "v"(xa[0]), "v"(xa[1]), "v"(xa[2]), "v"(xa[3]), "v"(xb[0]), "v"(xb[1]), "v"(xb[2]), "v"(xb[3]),
+                           "v"(xc[0]), "v"(xc[1]), "v"(xc[2]), "v"(xc[3]), "v"(xd[0]), "v"(xd[1]), "v"(xd[2]), "v"(xd[3]));
         } else if constexpr (KIND == 5) {
             // terms from global memory through the scalar cache (wave-uniform address): v_add_f32 v, s, v
             const float* __restrict__ tp = in + ((i * 64) & 960);
@@ -79,8 +93,8 @@ int main() {
     float h[1024]; for (int i = 0; i < 1024; ++i) h[i] = 1e-3f * (i % 7);
     hipMemcpy(in, h, 4096, hipMemcpyHostToDevice);
     const int iters = 2000;
-    const char* names[8] = {"v_add_f32_dpp wave_shr:1 (one chain)", "v_add_f32 VGPR term (one chain)", "v_add_f32, two chains interleaved (per pair)", "v_add_f32, terms by ds_read_b128 broadcast", "v_add_f32_dpp row_newbcast (64 terms per ds_read_b128)", "v_add_f32 with SGPR term (s_load)", "v_readlane + v_add_f32", "v_add_f32_dpp row_newbcast, no s_nop between the adds"};
-    for (int kind = 0; kind < 8; ++kind) {
+    const char* names[9] = {"v_add_f32_dpp wave_shr:1 (one chain)", "v_add_f32 VGPR term (one chain)", "v_add_f32, two chains interleaved (per pair)", "v_add_f32, terms by ds_read_b128 broadcast", "v_add_f32_dpp row_newbcast (64 terms per ds_read_b128)", "v_add_f32 with SGPR term (s_load)", "v_readlane + v_add_f32", "v_add_f32_dpp row_newbcast, no s_nop between the adds", "v_add_f32_dpp quad_perm broadcast, no s_nop (16 chains per wave)"};
+    for (int kind = 0; kind < 9; ++kind) {
         for (int rep = 0; rep < 2; ++rep) {
             if (kind == 0) hipLaunchKernelGGL(k_chain<0>, dim3(1), dim3(64), 0, 0, iters, in, out, clk);
             if (kind == 1) hipLaunchKernelGGL(k_chain<1>, dim3(1), dim3(64), 0, 0, iters, in, out, clk);
@@ -90,6 +104,7 @@ int main() {
             if (kind == 5) hipLaunchKernelGGL(k_chain<5>, dim3(1), dim3(64), 0, 0, iters, in, out, clk);
             if (kind == 6) hipLaunchKernelGGL(k_chain<6>, dim3(1), dim3(64), 0, 0, iters, in, out, clk);
             if (kind == 7) hipLaunchKernelGGL(k_chain<7>, dim3(1), dim3(64), 0, 0, iters, in, out, clk);
+            if (kind == 8) hipLaunchKernelGGL(k_chain<8>, dim3(1), dim3(64), 0, 0, iters, in, out, clk);
             hipDeviceSynchronize();
         }
         long long c; hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
