@@ -53,17 +53,21 @@ struct ExactArgs {
 
 // In place on A (k x k, LDS): choldc1 + choldcsl + the product and the mirror of
 // inverseMatrix_CholeskyMethod.  N is a second k x k LDS buffer, p holds the pivots.
-__device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, float* __restrict__ p, int k, uint32_t* spd_fail) {
+// Called by every thread of the workgroup (its barriers are workgroup barriers); threads beyond the first 64 only meet at them.
+// A and N are k x k with a row stride of ld = k + 1 floats: column walks (A[j][q] over lanes j) would otherwise hit one LDS bank 64 ways.
+__device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, float* __restrict__ p, int k, int ld, uint32_t* spd_fail) {
     const int lane = (int) threadIdx.x;
+    const bool act = lane < 64;
     // ---- choldc1: row i at a time; the j's of one i are independent
     for (int i = 0; i < k; ++i) {
         float sums[2] = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int j = i + lane + 64 * c;
-            if (j < k) {
-                float sum = A[i * k + j];
-                for (int q = i - 1; q >= 0; --q) sum = sub_rn(sum, mul_rn(A[i * k + q], A[j * k + q]));
+            if (act && j < k) {
+                float sum = A[i * ld + j];
+#pragma unroll 8
+                for (int q = i - 1; q >= 0; --q) sum = sub_rn(sum, mul_rn(A[i * ld + q], A[j * ld + q]));  // (unrolled: eight pairs of LDS reads in flight)
                 sums[c] = sum;
             }
         }
@@ -76,7 +80,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int j = i + lane + 64 * c;
-            if (j > i && j < k) A[j * k + i] = sums[c] / pi;
+            if (act && j > i && j < k) A[j * ld + i] = sums[c] / pi;
         }
         __syncthreads();
     }
@@ -85,106 +89,204 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
     // and writing L^-1 to N is the same computation)
     for (int c = 0; c < 2; ++c) {
         const int i = lane + 64 * c;
-        if (i < k) N[i * k + i] = 1.0f / p[i];
+        if (act && i < k) N[i * ld + i] = 1.0f / p[i];
     }
     __syncthreads();
     for (int j = 1; j < k; ++j) {
         double sum[2] = {0.0, 0.0};
-        for (int q = 0; q < j; ++q) {
-            const float ljq = A[j * k + q];  // broadcast
+        if (act) {
+            // q < i contributes nothing in the reference (its loop starts at q = i): a subtracted +0.0 leaves every double as it is, -0.0
+            // included, so the loop can be uniform over the lanes and unrolled (its LDS reads in flight eight at a time) -- entries of N
+            // above the diagonal are never written: whatever they hold is discarded by the select, not multiplied
+#pragma unroll 8
+            for (int q = 0; q < j; ++q) {
+                const float ljq = A[j * ld + q];  // broadcast
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int i = lane + 64 * c;
-                if (i < j && q >= i) sum[c] = sub_rn(sum[c], (double) mul_rn(ljq, N[q * k + i]));
+                for (int c = 0; c < 2; ++c) {
+                    const int i = lane + 64 * c;
+                    const float nqi = i < k ? N[q * ld + i] : 0.0f;
+                    const double term = (i < j && q >= i) ? (double) mul_rn(ljq, nqi) : 0.0;
+                    sum[c] = sub_rn(sum[c], term);
+                }
             }
         }
         const float pj = p[j];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int i = lane + 64 * c;
-            if (i < j) N[j * k + i] = (float) sum[c] / pj;
+            if (act && i < j) N[j * ld + i] = (float) sum[c] / pj;
         }
         __syncthreads();
     }
     // ---- A^-1 = L^-T L^-1: entry (i, j >= i) = sum over q >= j of N[q][i] * N[q][j]; the diagonal starts
-    // from N[i][i]^2, the others from 0.0f + the first product
-    for (int i = 0; i < k; ++i) {
+    // from N[i][i]^2, the others from 0.0f + the first product.  Every entry is independent of the others (N is only read, A only
+    // written): the rows i are dealt round-robin to ALL waves of the workgroup
+    const int nwv = (int) (blockDim.x >> 6), wv = lane >> 6, l64 = lane & 63;
+    for (int i = wv; i < k; i += nwv) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int j = i + lane + 64 * c;
+            const int j = i + l64 + 64 * c;
             if (j < k) {
                 float acc;
                 if (j == i) {
-                    acc = mul_rn(N[i * k + i], N[i * k + i]);
-                    for (int q = i + 1; q < k; ++q) acc = add_rn(acc, mul_rn(N[q * k + i], N[q * k + i]));
+                    acc = mul_rn(N[i * ld + i], N[i * ld + i]);
+#pragma unroll 8
+                    for (int q = i + 1; q < k; ++q) acc = add_rn(acc, mul_rn(N[q * ld + i], N[q * ld + i]));
                 } else {
                     acc = 0.0f;
-                    for (int q = j; q < k; ++q) acc = add_rn(acc, mul_rn(N[q * k + i], N[q * k + j]));
+#pragma unroll 8
+                    for (int q = j; q < k; ++q) acc = add_rn(acc, mul_rn(N[q * ld + i], N[q * ld + j]));
                 }
-                A[i * k + j] = acc;
-                A[j * k + i] = acc;
+                A[i * ld + j] = acc;
+                A[j * ld + i] = acc;
             }
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void k_als_exact(ExactArgs a) {
+// (r4) Mt_byM_multiply and subVector with the ENTRIES in the outer loop.  Every output (I, J) of the Gramian is its own chain
+//     SUM = 0; for K ascending: SUM += M[K][I] * M[K][J]          (unfused, src/ALS.cpp:66-79)
+// and the chains are independent of each other, so the loop nest can be turned inside out without touching a single rounding: a
+// gathered factor row is read ONCE (lane J takes M[K][J], the slice's M[K][I] come from the lanes that hold them: v_readlane) and advances every
+// chain by one term.  The first version ran the reference's own nest -- per (I, J) a pass over all entries, three loads per term:
+// 5.9 s per item half-sweep at the Netflix shape, 7.07 s per iteration.  The I range is cut into kExactWaves slices, one per wave of
+// the workgroup (the 237 k-entry column is one system: its chains are its duration); (I, J) and (J, I) are the same sequence of
+// products (a * b == b * a bit for bit), so the full square is written and no mirror is needed.  The right-hand side rides in wave 0.
+constexpr int kExactWaves = 4;
+constexpr int kExactBlock = 8;  // entries per block: their indices, ratings and factor rows are in flight while the block before is added up
+template <int S, int NC>  // S: rows I per wave (k <= S * kExactWaves); NC: column groups of 64 per lane
+__device__ __forceinline__ void exact_gramian(const ExactArgs& a, uint32_t lo, uint32_t hi, float* __restrict__ A, int ld, float* __restrict__ sv) {
+    constexpr int B = kExactBlock;
+    const int k = (int) a.k, lane = (int) (threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), I0 = wave * S;
+    const float* __restrict__ X = a.X;
+    const uint32_t* __restrict__ idx = a.idx;
+    const float* __restrict__ val = a.val;
+    float acc[S][NC];
+    float rhs[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        rhs[c] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < S; ++t) acc[t][c] = 0.0f;
+    }
+    if (I0 < k) {
+        auto rl = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+        // block n: entries lo + B n ... ; lane l < B holds the index / rating of entry l of the block (clamped to the last entry)
+        auto load_meta = [&](uint32_t q0, uint32_t& ids, float& vals) {
+            const uint32_t q = min(q0 + (uint32_t) (lane & (B - 1)), hi - 1);
+            ids = idx[q];
+            vals = val[q];
+        };
+        auto load_rows = [&](uint32_t ids, float (&x)[B][NC]) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const uint32_t r = (uint32_t) __builtin_amdgcn_readlane((int) ids, b);
+                const float* __restrict__ row = X + (size_t) r * k;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { const int J = lane + 64 * c; x[b][c] = J < k ? row[J] : 0.0f; }
+            }
+        };
+        auto add_block = [&](uint32_t q0, const float (&x)[B][NC], float vals) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                if (q0 + (uint32_t) b >= hi) break;  // (wave-uniform)
+#pragma unroll
+                for (int t = 0; t < S; ++t) {
+                    // M[K][I]: lane I % 64 of column group I / 64 holds it (a readlane with a wave-uniform lane index; rows past k read 0)
+                    const int I = I0 + t;
+                    float xi;
+                    if constexpr (NC == 1) {
+                        xi = rl(x[b][0], I & 63);
+                    } else {
+                        const float x0 = rl(x[b][0], I & 63), x1 = rl(x[b][NC - 1], I & 63);
+                        xi = I < 64 ? x0 : x1;
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[t][c] = add_rn(acc[t][c], mul_rn(xi, x[b][c]));
+                }
+                if (wave == 0) {
+                    const float v = rl(vals, b);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) rhs[c] = add_rn(rhs[c], mul_rn(v, x[b][c]));
+                }
+            }
+        };
+        // two sets that swap roles: the rows of block n + 1 and the indices of block n + 2 are in flight under the adds of block n
+        float xa[B][NC], xb[B][NC];
+        uint32_t ids_a, ids_b;
+        float vals_a, vals_b;
+        load_meta(lo, ids_a, vals_a);
+        load_meta(lo + B, ids_b, vals_b);
+        load_rows(ids_a, xa);
+        for (uint32_t q0 = lo; q0 < hi; q0 += 2 * B) {
+            load_rows(ids_b, xb);                            // block n + 1
+            const float va = vals_a;
+            load_meta(q0 + 2 * B, ids_a, vals_a);            // block n + 2
+            add_block(q0, xa, va);
+            if (q0 + B >= hi) break;
+            load_rows(ids_a, xa);                            // block n + 2
+            const float vb = vals_b;
+            load_meta(q0 + 3 * B, ids_b, vals_b);            // block n + 3
+            add_block(q0 + B, xb, vb);
+        }
+#pragma unroll
+        for (int t = 0; t < S; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int I = I0 + t, J = lane + 64 * c;
+                if (I < k && J < k) A[I * ld + J] = acc[t][c];
+            }
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const int J = lane + 64 * c; if (J < k) sv[J] = rhs[c]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * kExactWaves) void k_als_exact(ExactArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int k = (int) a.k, lane = (int) threadIdx.x;
+    const int k = (int) a.k, lane = (int) threadIdx.x, ld = k + 1;
     float* A = lds;
-    float* N = lds + (size_t) k * k;
-    float* p = N + (size_t) k * k;
+    float* N = lds + (size_t) k * ld;
+    float* p = N + (size_t) k * ld;
     float* sv = p + k;
     if (a.A_in) {
-        for (int e = lane; e < k * k; e += 64) A[e] = a.A_in[e];
+        for (int e = lane; e < k * k; e += (int) blockDim.x) A[(e / k) * ld + e % k] = a.A_in[e];
         __syncthreads();
-        exact_inverse(A, N, p, k, a.spd_fail);
-        for (int e = lane; e < k * k; e += 64) a.inv_out[e] = A[e];
+        exact_inverse(A, N, p, k, ld, a.spd_fail);
+        for (int e = lane; e < k * k; e += (int) blockDim.x) a.inv_out[e] = A[(e / k) * ld + e % k];
         return;
     }
     const uint32_t seg = blockIdx.x;
     const uint32_t lo = a.ptr[seg], hi = a.ptr[seg + 1];
     float* y = a.Y + (size_t) seg * k;
     if (hi == lo) {  // src/ALS.cpp:151-157
-        for (int c = lane; c < k; c += 64) y[c] = 0.0f;
+        for (int c = lane; c < k; c += (int) blockDim.x) y[c] = 0.0f;
         return;
     }
-    // Mt_byM_multiply: upper triangle, mirrored
-    for (int I = 0; I < k; ++I) {
-        for (int J = I + lane; J < k; J += 64) {
-            float sum = 0.0f;
-            for (uint32_t q = lo; q < hi; ++q) {
-                const float* row = a.X + (size_t) a.idx[q] * k;
-                sum = add_rn(sum, mul_rn(row[I], row[J]));
-            }
-            A[J * k + I] = sum;
-            A[I * k + J] = sum;
-        }
-    }
+    // Mt_byM_multiply + subVector (see exact_gramian)
+    if (k <= 16 * kExactWaves) exact_gramian<16, 1>(a, lo, hi, A, ld, sv);
+    else exact_gramian<32, 2>(a, lo, hi, A, ld, sv);
     __syncthreads();
-    for (int c = lane; c < k; c += 64) A[c * k + c] = add_rn(A[c * k + c], a.lambda);
+    for (int c = lane; c < k; c += (int) blockDim.x) A[c * ld + c] = add_rn(A[c * ld + c], a.lambda);
     __syncthreads();
-    exact_inverse(A, N, p, k, a.spd_fail);
-    for (int c = lane; c < k; c += 64) {
-        float s = 0.0f;
-        for (uint32_t q = lo; q < hi; ++q) s = add_rn(s, mul_rn(a.val[q], a.X[(size_t) a.idx[q] * k + c]));
-        sv[c] = s;
-    }
-    __syncthreads();
-    for (int c = lane; c < k; c += 64) {
+    // the right-hand side was accumulated next to the Gramian; the inverse overwrites A, not sv
+    exact_inverse(A, N, p, k, ld, a.spd_fail);
+    for (int c = lane; c < k; c += (int) blockDim.x) {
         float w = 0.0f;
-        for (int s = 0; s < k; ++s) w = add_rn(w, mul_rn(sv[s], A[c * k + s]));
+#pragma unroll 8
+        for (int s2 = 0; s2 < k; ++s2) w = add_rn(w, mul_rn(sv[s2], A[c * ld + s2]));
         y[c] = w;
     }
 }
 
 int launch_exact(const ExactArgs& a, uint32_t grid, hipStream_t st) {
-    const size_t lds_bytes = ((size_t) 2 * a.k * a.k + 2 * a.k) * sizeof(float);
+    const size_t lds_bytes = ((size_t) 2 * a.k * (a.k + 1) + 2 * a.k) * sizeof(float);  // (rows padded by one float: see exact_inverse)
     MFX_REQUIRE(lds_bytes <= 160 * 1024, "ALS as written: rank k = %u does not fit LDS", a.k);
     if (lds_bytes > 48 * 1024)
         MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-    hipLaunchKernelGGL(k_als_exact, dim3(grid), dim3(64), lds_bytes, st, a);
+    hipLaunchKernelGGL(k_als_exact, dim3(grid), dim3(64 * kExactWaves), lds_bytes, st, a);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
