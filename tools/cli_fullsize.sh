@@ -14,6 +14,13 @@ print(f"dataset written in {time.time() - t0:.1f} s", flush=True)
 PY
 ls -la $D | head -5
 for solver in "-CUDA" "-CUDA -ALS"; do
+  echo "== mfx_train $solver -k 64 -t 5 -l 0.05"
   ./cuda-recommender_amd/mfx_train $solver -k 64 -t 5 -l 0.05 $D 2>&1 | grep -v "^$" | tail -12
+done
+# (r4) the driver's comparison flow at full size: product leg, then the reference-order leg (bit-identical to the reference's CPU solver),
+# then the reference's own closing golden_compare between the two
+for solver in "-CUDA -OMP" "-CUDA -OMP -ALS"; do
+  echo "== mfx_train $solver -k 64 -t 3 -l 0.05"
+  ./cuda-recommender_amd/mfx_train $solver -k 64 -t 3 -l 0.05 $D 2>&1 | grep -v "^$" | tail -16
 done
 rm -rf $D
