@@ -54,7 +54,10 @@ struct ExactArgs {
 // In place on A (k x k, LDS): choldc1 + choldcsl + the product and the mirror of
 // inverseMatrix_CholeskyMethod.  N is a second k x k LDS buffer, p holds the pivots.
 // Called by every thread of the workgroup (its barriers are workgroup barriers); threads beyond the first 64 only meet at them.
-// A and N are k x k with a row stride of ld = k + 1 floats: column walks (A[j][q] over lanes j) would otherwise hit one LDS bank 64 ways.
+// A is k x k with a row stride of ld = k + 1 floats: column walks (A[j][q] over lanes j) would otherwise hit one LDS bank 64 ways.
+// N = L^-1 is lower triangular and stored packed, row q at q (q + 1) / 2: 25 KB of LDS per system at k = 64 instead of 34, six systems per CU
+// instead of four (the inverses' dependent chains are what the user half is made of).
+__device__ __forceinline__ int tri(int q) { return (q * (q + 1)) >> 1; }
 __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, float* __restrict__ p, int k, int ld, uint32_t* spd_fail) {
     const int lane = (int) threadIdx.x;
     const bool act = lane < 64;
@@ -89,7 +92,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
     // and writing L^-1 to N is the same computation)
     for (int c = 0; c < 2; ++c) {
         const int i = lane + 64 * c;
-        if (act && i < k) N[i * ld + i] = 1.0f / p[i];
+        if (act && i < k) N[tri(i) + i] = 1.0f / p[i];
     }
     __syncthreads();
     for (int j = 1; j < k; ++j) {
@@ -104,7 +107,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int i = lane + 64 * c;
-                    const float nqi = i < k ? N[q * ld + i] : 0.0f;
+                    const float nqi = N[tri(q) + min(i, q)];  // (i > q is not an entry of the packed triangle: an unconditional read of the diagonal instead; the term is discarded below)
                     const double term = (i < j && q >= i) ? (double) mul_rn(ljq, nqi) : 0.0;
                     sum[c] = sub_rn(sum[c], term);
                 }
@@ -114,7 +117,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int i = lane + 64 * c;
-            if (act && i < j) N[j * ld + i] = (float) sum[c] / pj;
+            if (act && i < j) N[tri(j) + i] = (float) sum[c] / pj;
         }
         __syncthreads();
     }
@@ -129,13 +132,13 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
             if (j < k) {
                 float acc;
                 if (j == i) {
-                    acc = mul_rn(N[i * ld + i], N[i * ld + i]);
+                    acc = mul_rn(N[tri(i) + i], N[tri(i) + i]);
 #pragma unroll 8
-                    for (int q = i + 1; q < k; ++q) acc = add_rn(acc, mul_rn(N[q * ld + i], N[q * ld + i]));
+                    for (int q = i + 1; q < k; ++q) acc = add_rn(acc, mul_rn(N[tri(q) + i], N[tri(q) + i]));
                 } else {
                     acc = 0.0f;
 #pragma unroll 8
-                    for (int q = j; q < k; ++q) acc = add_rn(acc, mul_rn(N[q * ld + i], N[q * ld + j]));
+                    for (int q = j; q < k; ++q) acc = add_rn(acc, mul_rn(N[tri(q) + i], N[tri(q) + j]));
                 }
                 A[i * ld + j] = acc;
                 A[j * ld + i] = acc;
@@ -244,12 +247,13 @@ __device__ __forceinline__ void exact_gramian(const ExactArgs& a, uint32_t lo, u
     }
 }
 
+template <bool BIG>  // BIG: 64 < k <= 128 (32 rows per wave, two column groups per lane: its registers must not cap the occupancy of the k <= 64 kernel)
 __global__ __launch_bounds__(64 * kExactWaves) void k_als_exact(ExactArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int k = (int) a.k, lane = (int) threadIdx.x, ld = k + 1;
     float* A = lds;
     float* N = lds + (size_t) k * ld;
-    float* p = N + (size_t) k * ld;
+    float* p = N + (size_t) tri(k);
     float* sv = p + k;
     if (a.A_in) {
         for (int e = lane; e < k * k; e += (int) blockDim.x) A[(e / k) * ld + e % k] = a.A_in[e];
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(64 * kExactWaves) void k_als_exact(ExactArgs a) {
         return;
     }
     // Mt_byM_multiply + subVector (see exact_gramian)
-    if (k <= 16 * kExactWaves) exact_gramian<16, 1>(a, lo, hi, A, ld, sv);
+    if constexpr (!BIG) exact_gramian<16, 1>(a, lo, hi, A, ld, sv);
     else exact_gramian<32, 2>(a, lo, hi, A, ld, sv);
     __syncthreads();
     for (int c = lane; c < k; c += (int) blockDim.x) A[c * ld + c] = add_rn(A[c * ld + c], a.lambda);
@@ -282,11 +286,14 @@ __global__ __launch_bounds__(64 * kExactWaves) void k_als_exact(ExactArgs a) {
 }
 
 int launch_exact(const ExactArgs& a, uint32_t grid, hipStream_t st) {
-    const size_t lds_bytes = ((size_t) 2 * a.k * (a.k + 1) + 2 * a.k) * sizeof(float);  // (rows padded by one float: see exact_inverse)
+    const size_t lds_bytes = ((size_t) a.k * (a.k + 1) + (size_t) a.k * (a.k + 1) / 2 + 2 * a.k) * sizeof(float);  // (A with rows padded by one float, N packed: see exact_inverse)
     MFX_REQUIRE(lds_bytes <= 160 * 1024, "ALS as written: rank k = %u does not fit LDS", a.k);
+    const bool big = a.k > 16 * kExactWaves;
     if (lds_bytes > 48 * 1024)
-        MFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_als_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-    hipLaunchKernelGGL(k_als_exact, dim3(grid), dim3(64 * kExactWaves), lds_bytes, st, a);
+        MFX_HIP(hipFuncSetAttribute(big ? reinterpret_cast<const void*>(k_als_exact<true>) : reinterpret_cast<const void*>(k_als_exact<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+    if (big) hipLaunchKernelGGL(k_als_exact<true>, dim3(grid), dim3(64 * kExactWaves), lds_bytes, st, a);
+    else hipLaunchKernelGGL(k_als_exact<false>, dim3(grid), dim3(64 * kExactWaves), lds_bytes, st, a);
     MFX_HIP(hipGetLastError());
     return MFX_OK;
 }
