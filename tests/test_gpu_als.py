@@ -292,3 +292,22 @@ def test_als_half_gather_table_past_the_32_bit_offsets(mfx):
     val = rng.uniform(1.0, 5.0, int(ptr[-1])).astype(np.float32)
     Y = mfx.als_half(ptr, idx, val, X, k, 0.05)
     assert relerr(Y, _solve_f64(ptr, idx, val, X, k, 0.05)) < 2e-3
+
+
+@pytest.mark.parametrize("k", [8, 64, 72])
+def test_als_as_written_segment_ends_bit_exact(mfx, orc, k):
+    """The as-written mode walks a segment in blocks of eight entries with the next blocks' indices, ratings and factor rows in flight
+    (als_exact.hip, exact_gramian): segments of every length around the block and double-block boundaries (1 .. 40 entries, an empty
+    one, 2062, 3, 16), the last one ending exactly at the end of the arrays -- bit-identical to the oracle, which is the reference's
+    own loop nest."""
+    rng = np.random.default_rng(50 + k)
+    lens = list(range(1, 41)) + [0, 17, 2049 + 13, 3, 16]
+    ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    nnz, G = int(ptr[-1]), 500
+    idx = rng.integers(0, G, nnz).astype(np.uint32)
+    val = rng.uniform(1.0, 5.0, nnz).astype(np.float32)
+    X = rng.uniform(-1.0, 1.0, (G, k)).astype(np.float32)
+    Y = mfx.als_half(ptr, idx, val, X, k, 0.05, variant=0)
+    ref = orc.als_half(ptr, idx, val, X, k, 0.05, 2)
+    assert np.array_equal(bits(Y), bits(ref))
+    assert np.array_equal(Y[40], np.zeros(k, np.float32))  # the empty segment (src/ALS.cpp:151-157)
