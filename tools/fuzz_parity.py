@@ -153,6 +153,11 @@ for case in range(a.cases):
             H0 = mfx.initial_col(d.cols, ka)
             Y = mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, ka, lam)
             Yo = orc.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, ka, lam, 2)
+            # (r4) the as-written mode (als_exact.hip: entries in the outer loop, four waves per system): the oracle's bits
+            Yx = mfx.als_half(d.csr_row_ptr, d.csr_col_idx, d.csr_val, H0, ka, lam, variant=0)
+            if not np.array_equal(Yx.view(np.uint32), Yo.view(np.uint32)):
+                fails.append(f"ALS-AS-WRITTEN k={ka} {tag}: not bit-identical to the oracle (max diff {float(np.abs(Yx - Yo).max()):.2e})")
+            kinds["als_as_written"] = kinds.get("als_as_written", 0) + 1
             segs = rng.choice(d.rows, size=min(d.rows, 800), replace=False)
             H64 = H0.astype(np.float64)
             e_gpu = e_orc = 0.0
