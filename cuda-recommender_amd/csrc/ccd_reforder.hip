@@ -711,8 +711,8 @@ int launch_ref_owner(FlatMode mode, const SegStreamDev& s, const uint32_t* order
     a.item0 = std::min(ref_split_items(nlong), a.nitems);
     a.lambda = f.lambda; a.out_vec = f.out_vec; a.pack2 = f.pack2; a.next_vec = f.next_vec; a.pack4 = f.pack4;
     const bool side = a.item0 > 0 && rs.side && rs.fork && rs.join && a.item0 < a.nitems;
-    // the split kernel goes FIRST, on the main stream; the quad kernel follows on the side stream (behind an event recorded after the
-    // split launch is enqueued, not after it completes)
+    // the split kernel is enqueued FIRST, on the main stream; the quad kernel goes to the side stream behind an event recorded on the main
+    // stream just before (so both wait for the same earlier work and then run side by side, the split workgroups placed first)
     hipStream_t st_split = rs.main, st_quad = side ? rs.side : rs.main;
     if (a.item0 > 0) {
         static std::mutex m;
