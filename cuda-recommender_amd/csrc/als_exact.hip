@@ -58,14 +58,16 @@ struct ExactArgs {
 // N = L^-1 is lower triangular and stored packed, row q at q (q + 1) / 2: 25 KB of LDS per system at k = 64 instead of 34, six systems per CU
 // instead of four (the inverses' dependent chains are what the user half is made of).
 __device__ __forceinline__ int tri(int q) { return (q * (q + 1)) >> 1; }
+template <int NC>  // column groups of 64 per lane: 1 for k <= 64 (the second group's chains would be computed and thrown away: choldcsl, 58 % of an
+                   // inverse, runs its selects for every group it is given -- k = 64: 226 -> see profiles/r04_als_exact_time.txt)
 __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, float* __restrict__ p, int k, int ld, uint32_t* spd_fail) {
     const int lane = (int) threadIdx.x;
     const bool act = lane < 64;
     // ---- choldc1: row i at a time; the j's of one i are independent
     for (int i = 0; i < k; ++i) {
-        float sums[2] = {0.f, 0.f};
+        float sums[NC] = {};
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int j = i + lane + 64 * c;
             if (act && j < k) {
                 float sum = A[i * ld + j];
@@ -81,7 +83,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
         __syncthreads();
         const float pi = p[i];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int j = i + lane + 64 * c;
             if (act && j > i && j < k) A[j * ld + i] = sums[c] / pi;
         }
@@ -90,13 +92,13 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
     // ---- choldcsl, second loop: column i of L^-1 (lane = column; the reference works in place, column by
     // column, and column i only ever reads columns >= i of L, which it has not touched yet: reading L from A
     // and writing L^-1 to N is the same computation)
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int i = lane + 64 * c;
         if (act && i < k) N[tri(i) + i] = 1.0f / p[i];
     }
     __syncthreads();
     for (int j = 1; j < k; ++j) {
-        double sum[2] = {0.0, 0.0};
+        double sum[NC] = {};
         if (act) {
             // q < i contributes nothing in the reference (its loop starts at q = i): a subtracted +0.0 leaves every double as it is, -0.0
             // included, so the loop can be uniform over the lanes and unrolled (its LDS reads in flight eight at a time) -- entries of N
@@ -105,7 +107,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
             for (int q = 0; q < j; ++q) {
                 const float ljq = A[j * ld + q];  // broadcast
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < NC; ++c) {
                     const int i = lane + 64 * c;
                     const float nqi = N[tri(q) + min(i, q)];  // (i > q is not an entry of the packed triangle: an unconditional read of the diagonal instead; the term is discarded below)
                     const double term = (i < j && q >= i) ? (double) mul_rn(ljq, nqi) : 0.0;
@@ -115,7 +117,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
         }
         const float pj = p[j];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int i = lane + 64 * c;
             if (act && i < j) N[tri(j) + i] = (float) sum[c] / pj;
         }
@@ -127,7 +129,7 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
     const int nwv = (int) (blockDim.x >> 6), wv = lane >> 6, l64 = lane & 63;
     for (int i = wv; i < k; i += nwv) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int j = i + l64 + 64 * c;
             if (j < k) {
                 float acc;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(64 * kExactWaves) void k_als_exact(ExactArgs a) {
     if (a.A_in) {
         for (int e = lane; e < k * k; e += (int) blockDim.x) A[(e / k) * ld + e % k] = a.A_in[e];
         __syncthreads();
-        exact_inverse(A, N, p, k, ld, a.spd_fail);
+        exact_inverse<BIG ? 2 : 1>(A, N, p, k, ld, a.spd_fail);
         for (int e = lane; e < k * k; e += (int) blockDim.x) a.inv_out[e] = A[(e / k) * ld + e % k];
         return;
     }
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64 * kExactWaves) void k_als_exact(ExactArgs a) {
     for (int c = lane; c < k; c += (int) blockDim.x) A[c * ld + c] = add_rn(A[c * ld + c], a.lambda);
     __syncthreads();
     // the right-hand side was accumulated next to the Gramian; the inverse overwrites A, not sv
-    exact_inverse(A, N, p, k, ld, a.spd_fail);
+    exact_inverse<BIG ? 2 : 1>(A, N, p, k, ld, a.spd_fail);
     for (int c = lane; c < k; c += (int) blockDim.x) {
         float w = 0.0f;
 #pragma unroll 8
