@@ -63,43 +63,47 @@ template <int NC>  // column groups of 64 per lane: 1 for k <= 64 (the second gr
 __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, float* __restrict__ p, int k, int ld, uint32_t* spd_fail) {
     const int lane = (int) threadIdx.x;
     const bool act = lane < 64;
-    // ---- choldc1: row i at a time; the j's of one i are independent
-    for (int i = 0; i < k; ++i) {
-        float sums[NC] = {};
+    // choldc1 and choldcsl are ONE wave's work (64 lanes = the independent outputs of a step), so they need no workgroup barrier at
+    // all: a wave's LDS operations execute in order, what its lanes wrote in one step its lanes read in the next.  The first version
+    // met the other three waves twice per row and once per column -- ~190 barriers per system, a fifth of an inverse.  The pivot goes
+    // from lane 0 to the others by v_readlane (the same float, so the same sqrtf).
+    if (act) {
+        // ---- choldc1: row i at a time; the j's of one i are independent
+        for (int i = 0; i < k; ++i) {
+            float sums[NC] = {};
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int j = i + lane + 64 * c;
-            if (act && j < k) {
-                float sum = A[i * ld + j];
+            for (int c = 0; c < NC; ++c) {
+                const int j = i + lane + 64 * c;
+                if (j < k) {
+                    float sum = A[i * ld + j];
 #pragma unroll 8
-                for (int q = i - 1; q >= 0; --q) sum = sub_rn(sum, mul_rn(A[i * ld + q], A[j * ld + q]));  // (unrolled: eight pairs of LDS reads in flight)
-                sums[c] = sum;
+                    for (int q = i - 1; q >= 0; --q) sum = sub_rn(sum, mul_rn(A[i * ld + q], A[j * ld + q]));  // (unrolled: eight pairs of LDS reads in flight)
+                    sums[c] = sum;
+                }
             }
-        }
-        if (lane == 0) {
-            if (sums[0] <= 0.f) atomicAdd(spd_fail, 1u);  // the reference prints " a is not positive definite!" and carries on
-            p[i] = sqrtf(sums[0]);
-        }
-        __syncthreads();
-        const float pi = p[i];
+            const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sums[0]), 0));
+            const float pi = sqrtf(piv);
+            if (lane == 0) {
+                if (piv <= 0.f) atomicAdd(spd_fail, 1u);  // the reference prints " a is not positive definite!" and carries on
+                p[i] = pi;
+            }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int j = i + lane + 64 * c;
-            if (act && j > i && j < k) A[j * ld + i] = sums[c] / pi;
+            for (int c = 0; c < NC; ++c) {
+                const int j = i + lane + 64 * c;
+                if (j > i && j < k) A[j * ld + i] = sums[c] / pi;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (compiler ordering of the LDS stores above against the loads below)
         }
-        __syncthreads();
-    }
-    // ---- choldcsl, second loop: column i of L^-1 (lane = column; the reference works in place, column by
-    // column, and column i only ever reads columns >= i of L, which it has not touched yet: reading L from A
-    // and writing L^-1 to N is the same computation)
-    for (int c = 0; c < NC; ++c) {
-        const int i = lane + 64 * c;
-        if (act && i < k) N[tri(i) + i] = 1.0f / p[i];
-    }
-    __syncthreads();
-    for (int j = 1; j < k; ++j) {
-        double sum[NC] = {};
-        if (act) {
+        // ---- choldcsl, second loop: column i of L^-1 (lane = column; the reference works in place, column by
+        // column, and column i only ever reads columns >= i of L, which it has not touched yet: reading L from A
+        // and writing L^-1 to N is the same computation)
+        for (int c = 0; c < NC; ++c) {
+            const int i = lane + 64 * c;
+            if (i < k) N[tri(i) + i] = 1.0f / p[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int j = 1; j < k; ++j) {
+            double sum[NC] = {};
             // q < i contributes nothing in the reference (its loop starts at q = i): a subtracted +0.0 leaves every double as it is, -0.0
             // included, so the loop can be uniform over the lanes and unrolled (its LDS reads in flight eight at a time) -- entries of N
             // above the diagonal are never written: whatever they hold is discarded by the select, not multiplied
@@ -114,15 +118,16 @@ __device__ void exact_inverse(float* __restrict__ A, float* __restrict__ N, floa
                     sum[c] = sub_rn(sum[c], term);
                 }
             }
-        }
-        const float pj = p[j];
+            const float pj = p[j];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int i = lane + 64 * c;
-            if (act && i < j) N[tri(j) + i] = (float) sum[c] / pj;
+            for (int c = 0; c < NC; ++c) {
+                const int i = lane + 64 * c;
+                if (i < j) N[tri(j) + i] = (float) sum[c] / pj;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         }
-        __syncthreads();
     }
+    __syncthreads();
     // ---- A^-1 = L^-T L^-1: entry (i, j >= i) = sum over q >= j of N[q][i] * N[q][j]; the diagonal starts
     // from N[i][i]^2, the others from 0.0f + the first product.  Every entry is independent of the others (N is only read, A only
     // written): the rows i are dealt round-robin to ALL waves of the workgroup
